@@ -1,0 +1,295 @@
+"""CPU oracle for the template-scoring path -- TEST INFRASTRUCTURE ONLY.
+
+Python face of oracle/tsr_oracle.c (ctypes) plus NumPy restatements of the
+reference's Python-2 glue that cannot be imported under Python 3.  Only
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product path (template-speech-recognition_amd/) never does.
+
+Pinned bit-for-bit against the compiled reference in oracle/_ref (see
+oracle/build_ref.py) and the golden vectors under tests/golden/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_HERE, "tsr_oracle.c")
+_LIB = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+_i64, _i32, _int = C.c_int64, C.c_int32, C.c_int
+_p = C.c_void_p
+
+
+def build(force=False):
+    """gcc -O2 -ffp-contract=off (no -ffast-math): summation order preserved."""
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(_SRC):
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared",
+                               "-fvisibility=hidden", "-o", _LIB, _SRC, "-lm"])
+    return _LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        _lib = C.CDLL(_LIB)
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+# ----------------------------------------------------------------------------
+# compute_likelihood_linear_filter.pyx
+# ----------------------------------------------------------------------------
+def detect(F, LF):
+    """compute_likelihood_linear_filter.pyx:135-176. F u8 [T,...], LF f32 [L,...]."""
+    F = _c(F, np.uint8)
+    LF = _c(LF, np.float32)
+    T, L = F.shape[0], LF.shape[0]
+    D = int(np.prod(F.shape[1:]))
+    assert int(np.prod(LF.shape[1:])) == D and T >= L
+    out = np.empty(T, np.float32)
+    lib().tsr_oracle_detect_u8(_ptr(F), _i64(T), _i64(D), _ptr(LF), _i64(L), _ptr(out))
+    return out
+
+
+def detect_float(F, LF):
+    """:178-219 / :281-318 / :322-359 (3-D or 2-D f32 features)."""
+    F = _c(F, np.float32)
+    LF = _c(LF, np.float32)
+    T, L = F.shape[0], LF.shape[0]
+    D = int(np.prod(F.shape[1:]))
+    assert int(np.prod(LF.shape[1:])) == D and T >= L
+    out = np.empty(T, np.float32)
+    lib().tsr_oracle_detect_f32(_ptr(F), _i64(T), _i64(D), _ptr(LF), _i64(L), _ptr(out))
+    return out
+
+
+detect_float2d = detect_float
+detect_spectral = detect_float
+
+
+def detect_float_max(F, LF, cs):
+    """:221-278. LF f32 [M,L,...], cs f32 [M] -> (f32 [T], u16 [T])."""
+    F = _c(F, np.float32)
+    LF = _c(LF, np.float32)
+    cs = _c(cs, np.float32)
+    T, M, L = F.shape[0], LF.shape[0], LF.shape[1]
+    D = int(np.prod(F.shape[1:]))
+    assert int(np.prod(LF.shape[2:])) == D and T >= L and cs.shape == (M,)
+    out = np.empty(T, np.float32)
+    ids = np.empty(T, np.uint16)
+    lib().tsr_oracle_detect_float_max(_ptr(F), _i64(T), _i64(D), _ptr(LF), _i64(M), _i64(L),
+                                      _ptr(cs), _ptr(out), _ptr(ids))
+    return out, ids
+
+
+def get_max_detect_examples(F, LF, lengths):
+    """:21-76. F u8 [N,T,...], LF f64 [L,...], lengths i64 [N] -> f64 [N]."""
+    F = _c(F, np.uint8)
+    LF = _c(LF, np.float64)
+    lengths = _c(lengths, np.int64)
+    N, T, L = F.shape[0], F.shape[1], LF.shape[0]
+    D = int(np.prod(F.shape[2:]))
+    out = np.empty(N, np.float64)
+    lib().tsr_oracle_get_max_detect_examples(_ptr(F), _i64(N), _i64(T), _i64(D), _ptr(LF),
+                                             _i64(L), _ptr(lengths), _ptr(out))
+    return out
+
+
+def pack_bank(linear_filters_cs):
+    """((W_m f32 [L_m,...], c_m), ...) -> (W_cat f32, woff i64 [M], L i32 [M], c f64 [M], D)."""
+    Ws = [np.ascontiguousarray(w, np.float32) for w, _ in linear_filters_cs]
+    D = int(np.prod(Ws[0].shape[1:]))
+    L = np.array([w.shape[0] for w in Ws], np.int32)
+    woff = np.concatenate(([0], np.cumsum(L.astype(np.int64) * D)[:-1])).astype(np.int64)
+    W_cat = np.concatenate([w.reshape(-1) for w in Ws]).astype(np.float32)
+    c = np.array([float(cc) for _, cc in linear_filters_cs], np.float64)
+    return W_cat, woff, L, c, D
+
+
+def score_bank(E, linear_filters_cs):
+    """get_train_data.py:962-992 epilogue for ONE utterance -> (scores f32 [T], ids i32 [T])."""
+    F = _c(E, np.uint8)
+    T = F.shape[0]
+    W_cat, woff, L, c, D = pack_bank(linear_filters_cs)
+    assert int(np.prod(F.shape[1:])) == D
+    scores = np.empty(T, np.float32)
+    ids = np.empty(T, np.int32)
+    scratch = np.empty(T, np.float32)
+    lib().tsr_oracle_score_bank_u8(_ptr(F), _i64(T), _i64(D), _ptr(W_cat), _ptr(woff), _ptr(L),
+                                   _ptr(c), _i64(len(L)), _ptr(scores), _ptr(ids), _ptr(scratch))
+    return scores, ids
+
+
+def score_bank_all(E, linear_filters_cs):
+    """detect(E, W_m) + f32(c_m) for every template -> f32 [M,T]."""
+    F = _c(E, np.uint8)
+    T = F.shape[0]
+    W_cat, woff, L, c, D = pack_bank(linear_filters_cs)
+    out = np.empty((len(L), T), np.float32)
+    lib().tsr_oracle_score_bank_all_u8(_ptr(F), _i64(T), _i64(D), _ptr(W_cat), _ptr(woff),
+                                       _ptr(L), _ptr(c), _i64(len(L)), _ptr(out))
+    return out
+
+
+def score_corpus(feats_cat, frame_offsets, linear_filters_cs):
+    """Serial corpus loop (get_train_data.py:1269) -> (scores f32 [sumT], ids i32 [sumT])."""
+    feats = _c(feats_cat, np.uint8)
+    foff = _c(frame_offsets, np.int64)
+    N = len(foff) - 1
+    W_cat, woff, L, c, D = pack_bank(linear_filters_cs)
+    total = int(foff[-1])
+    assert feats.size == total * D
+    scores = np.empty(total, np.float32)
+    ids = np.empty(total, np.int32)
+    scratch = np.empty(int(np.max(np.diff(foff))) if N else 1, np.float32)
+    lib().tsr_oracle_score_corpus_u8(_ptr(feats), _ptr(foff), _i64(N), _i64(D), _ptr(W_cat),
+                                     _ptr(woff), _ptr(L), _ptr(c), _i64(len(L)), _ptr(scores),
+                                     _ptr(ids), _ptr(scratch))
+    return scores, ids
+
+
+# ----------------------------------------------------------------------------
+# code_parts.pyx / spread_waliji_patches.pyx
+# ----------------------------------------------------------------------------
+def _code_parts(fn, X, log_parts, log_invparts, threshold):
+    X = _c(X, np.uint8)
+    lp = _c(log_parts, np.float64)
+    lip = _c(log_invparts, np.float64)
+    X0, X1, E = X.shape
+    K, P0, P1, E2 = lp.shape
+    assert E2 == E and lip.shape == lp.shape and X0 >= P0 and X1 >= P1
+    out = np.empty((X0 - P0 + 1, X1 - P1 + 1, K + 1), np.float64)
+    fn(_ptr(X), _i64(X0), _i64(X1), _i64(E), _ptr(lp), _ptr(lip), _i64(K), _i64(P0), _i64(P1),
+       _int(int(threshold)), _ptr(out))
+    return out
+
+
+def code_parts(X, log_parts, log_invparts, threshold):
+    """code_parts.pyx:70-135."""
+    return _code_parts(lib().tsr_oracle_code_parts, X, log_parts, log_invparts, threshold)
+
+
+def code_parts_fast(X, log_parts, log_invparts, threshold):
+    """code_parts.pyx:247-295."""
+    return _code_parts(lib().tsr_oracle_code_parts_fast, X, log_parts, log_invparts, threshold)
+
+
+def argmax_last(A):
+    """np.argmax(A, -1) (first maximum), get_train_data.py:2621, :184."""
+    A = _c(A, np.float64)
+    out = np.empty(A.shape[:-1], np.int64)
+    lib().tsr_oracle_argmax_last(_ptr(A), _i64(out.size), _i64(A.shape[-1]), _ptr(out))
+    return out
+
+
+def spread_patches(X, spread_0_dim, spread_1_dim, num_parts):
+    """code_parts.pyx:406-457 == spread_waliji_patches.pyx:15-59."""
+    X = _c(X, np.int64)
+    out = np.empty(X.shape + (int(num_parts),), np.uint8)
+    lib().tsr_oracle_spread_patches(_ptr(X), _i64(X.shape[0]), _i64(X.shape[1]),
+                                    _int(int(spread_0_dim)), _int(int(spread_1_dim)),
+                                    _i64(int(num_parts)), _ptr(out))
+    return out
+
+
+spread_waliji_patches = spread_patches
+
+
+def spread_graph_patches(X, part_graph):
+    """code_parts.pyx:459-503; mutates X in place, returns None."""
+    assert X.dtype == np.uint8 and X.flags.c_contiguous
+    g = _c(part_graph, np.uint8)
+    lib().tsr_oracle_spread_graph_patches(_ptr(X), _i64(X.shape[0]), _i64(X.shape[1]),
+                                          _i64(X.shape[2]), _ptr(g))
+
+
+# ----------------------------------------------------------------------------
+# NumPy restatements of the Python-2 glue (cannot be imported under Python 3)
+# ----------------------------------------------------------------------------
+def score_template_background_section(template, bgd, E):
+    """test_template.py:25-41 with front/back pad 0: (sum E*log W, C), f64.
+    template, E: [D, L] (features x time); bgd: [D]."""
+    assert E.shape[1] == template.shape[1]
+    T = np.asarray(template, np.float64)
+    U_bgd = np.tile(np.asarray(bgd, np.float64), (T.shape[1], 1)).transpose()
+    C_exp_inv_long = (1. - T) / (1. - U_bgd)
+    Cc = np.log(C_exp_inv_long).sum()
+    expW = (T / U_bgd) / C_exp_inv_long
+    return (E * np.log(expW)).sum(), Cc
+
+
+def construct_linear_filter(T, bgd, min_prob=.01, all_cs=False):
+    """estimate_template.py:230-251: W = log((T/B)/((1-T)/(1-B))) -> f32, c f64."""
+    T = np.clip(np.asarray(T, np.float64), min_prob, 1 - min_prob)
+    Bgd = np.tile(np.asarray(bgd, np.float64), (T.shape[0],) + (1,) * (T.ndim - 1))
+    C_exp_inv = (1. - T) / (1. - Bgd)
+    if all_cs:
+        c = np.cumsum(np.log(C_exp_inv.reshape(len(C_exp_inv), -1)).sum(1))
+    else:
+        c = np.log(C_exp_inv).sum()
+    expW = (T / Bgd) / C_exp_inv
+    return np.log(expW).astype(np.float32), c
+
+
+def construct_linear_filters(Ts, bgd, min_prob=.01, all_cs=False):
+    """estimate_template.py:156-172 (non-spectral branch)."""
+    return tuple(construct_linear_filter(np.clip(T, min_prob, 1 - min_prob),
+                                         np.clip(bgd, min_prob, 1 - min_prob), all_cs=all_cs)
+                 for T in Ts)
+
+
+def reorg_part_for_fast_filtering(part, feature_types=8):
+    """get_train_data.py:41-51: [feature_types*H, T] -> [T, H, feature_types]."""
+    H = part.shape[0] // feature_types
+    return np.array([part[i * H:(i + 1) * H].T for i in range(feature_types)]).swapaxes(0, 1).swapaxes(1, 2)
+
+
+def collapse_to_grid(E_coded, grid_time, grid_frequency):
+    """get_train_data.py:72-81."""
+    return E_coded[::grid_time, ::grid_frequency]
+
+
+def get_part_features(E, logParts, logInvParts, bernsteinEdgeThreshold, spreadRadiusX,
+                      spreadRadiusY, numParts, partGraph=None):
+    """get_train_data.py:2619-2631 (the non-mag/aux branch)."""
+    out = code_parts(np.asarray(E).astype(np.uint8), logParts, logInvParts, bernsteinEdgeThreshold)
+    max_responses = argmax_last(out)
+    spread = spread_patches(max_responses, spreadRadiusX, spreadRadiusY, numParts)
+    if partGraph is not None:
+        spread_graph_patches(spread, partGraph)
+    return spread
+
+
+def waliji_feature_map(E2, log_part_blocks, log_invpart_blocks):
+    """get_train_data.py:183-191: code_parts_fast(thr 10) -> argmax -> spread (radius =
+    patch dims) -> collapse_to_grid(patch dims).  E2 is the [T,F,8] edge map."""
+    F = code_parts_fast(np.asarray(E2).astype(np.uint8), log_part_blocks, log_invpart_blocks, 10)
+    F = argmax_last(F)
+    F = spread_patches(F, log_part_blocks.shape[1], log_part_blocks.shape[2],
+                       log_part_blocks.shape[0])
+    return collapse_to_grid(F, log_part_blocks.shape[1], log_part_blocks.shape[2])
+
+
+def compute_detection_E(E, linear_filters_cs):
+    """get_train_data.py:962-992 written with NumPy on top of detect(): used to pin
+    tsr_oracle_score_bank_u8 (f32 + f32(c), strict '>' ids, np.maximum)."""
+    E = np.asarray(E).astype(np.uint8)
+    row = detect(E, linear_filters_cs[0][0]) + np.float32(linear_filters_cs[0][1])
+    ids = np.zeros(E.shape[0], np.int32)
+    for m, (W, c) in enumerate(linear_filters_cs[1:], start=1):
+        v = detect(E, W) + np.float32(c)
+        ids[v > row] = m
+        row = np.maximum(v, row)
+    return row.astype(np.float32), ids
