@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- scored frames/s of the template-scoring hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode fast|exact]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8(d) "config 2"), per GPU:
+1 000 synthetic utterances x 200 frames of binary edge features (45 x 8 = 360
+per frame), scored against an 8-template bank (L = 32).  One step = one scoring
+pass over that corpus with features, bank and outputs resident in HBM.  With N
+GPUs every rank scores its own 1 000 utterances (weak scaling; utterances are
+independent, no data-path collective); the bank is generated on rank 0 and
+broadcast once with RCCL before the timed region.
+
+The product path is libtsr_hip.so through ctypes (no torch).  torch.distributed
+(gloo, CPU) is used only as the host control plane for N > 1: rendezvous,
+barrier, max-over-ranks of the time, hand-over of the RCCL unique id.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "template-speech-recognition_amd"))
+
+import tsr_hip  # noqa: E402  (loads libtsr_hip.so before anything else touches HIP)
+from tsr_hip import synth  # noqa: E402
+
+CFG = dict(N=1000, T=200, F=45, E=8, M=8, L=32)
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+MFMA_I8_PEAK_TOPS = 5000.0    # dense int8 MFMA = 2x bf16 (~2.5 PF) per clock
+VALU_F32_PEAK_TFLOPS = 157.3
+ALG_BYTES_PER_FRAME = CFG["F"] * CFG["E"] + 6  # D u8 in + f32 max + 2-byte id
+
+
+def cpu_baseline(corpus, budget_s=12.0):
+    """Single-core CPU baseline on a bounded sample of the same workload: the
+    reference's compiled Cython kernels when oracle/_ref travelled with the repo
+    ("reference"), else the C restatement ("port").  Reported, never the target."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import build_ref
+    import oracle
+    oracle.build()
+    feats, offs, bank = corpus["feats"], corpus["offsets"], corpus["bank"]
+    ref = build_ref.load()
+    kind = "reference" if ref is not None else "port"
+
+    def run(n0, n1):
+        if ref is not None:
+            cllf = ref[0]
+            for n in range(n0, n1):
+                E = feats[offs[n]:offs[n + 1]]
+                row = cllf.detect(E, bank[0][0]) + np.float32(bank[0][1])
+                for W, c in bank[1:]:
+                    row = np.maximum(cllf.detect(E, W) + np.float32(c), row)
+        else:
+            oracle.score_corpus(feats[offs[n0]:offs[n1]], offs[n0:n1 + 1] - offs[n0], bank)
+
+    t0 = time.perf_counter()
+    run(0, 8)
+    per_utt = (time.perf_counter() - t0) / 8
+    n = int(max(16, min(len(offs) - 1, budget_s / max(per_utt, 1e-6))))
+    t0 = time.perf_counter()
+    run(0, n)
+    dt = time.perf_counter() - t0
+    frames = int(offs[n] - offs[0])
+    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": kind,
+            "sample": "%d of %d utterances (%d frames) of the same corpus, %.1f s, one thread"
+                      % (n, len(offs) - 1, frames, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", choices=["auto", "fast", "exact"], default=os.environ.get("TSR_BENCH_MODE", "auto"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N")
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+
+    ctx = tsr_hip.Context(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # host control plane only (gloo, CPU tensors)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    # ---- data: every rank its own utterances, one bank for all ----------------------
+    corpus = synth.corpus(2 + 1000 * rank, **CFG)
+    if world > 1:
+        ids = [tsr_hip.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.dist_init(ids[0], world, rank)
+        if rank != 0:  # same geometry, weights to be overwritten by rank 0's
+            corpus["bank"] = tuple((np.zeros_like(W), 0.0) for W, _ in corpus["bank"])
+    bank = tsr_hip.Bank(corpus["bank"], ctx=ctx)
+    if world > 1:
+        bank.broadcast(0)  # RCCL over xGMI; the only collective on this path
+    dev_corpus = tsr_hip.Corpus(corpus["feats"], corpus["offsets"], ctx=ctx)
+    if args.mode == "auto":  # the MFMA path when this build has it, else the exact VALU path
+        try:
+            dev_corpus.score(bank, tsr_hip.TSR_FAST)
+            ctx.sync()
+            args.mode = "fast"
+        except tsr_hip.TsrError as e:
+            if e.status != 4:
+                raise
+            args.mode = "exact"
+    flags = tsr_hip.TSR_FAST if args.mode == "fast" else tsr_hip.TSR_EXACT
+    frames = int(corpus["offsets"][-1])
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        dev_corpus.score(bank, flags)
+    barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        dev_corpus.score(bank, flags)
+    kernel_ms = ctx.timer_stop()          # hipEvents on the launch stream
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([wall, kernel_ms], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, kernel_ms = float(t[0]), float(t[1])
+
+    # ---- parity spot check on what was just computed (rank 0, oracle as checker) -----
+    scores, ids_ = dev_corpus.download()
+    if rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle
+        offs = corpus["offsets"]
+        so, ao = oracle.score_corpus(corpus["feats"][:offs[4]], offs[:5], corpus["bank"])
+        err = float(np.max(np.abs(scores[:offs[4]] - so) / np.maximum(np.abs(so), 1.0)))
+        if err > 1e-4:
+            raise SystemExit("parity check failed in bench: rel err %.3g" % err)
+
+    if rank == 0:
+        per_launch_s = kernel_ms * 1e-3 / args.steps
+        alg_bytes = ALG_BYTES_PER_FRAME * frames
+        achieved = alg_bytes / per_launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.mode)
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        sumL = CFG["M"] * CFG["L"]
+        alg_flops = 2.0 * CFG["F"] * CFG["E"] * sumL * (CFG["T"] - CFG["L"] + 1) * CFG["N"]
+        out = {
+            "metric": "scored frames/sec (whole node) + achieved HBM GB/s vs roofline",
+            "value": frames * world * args.steps / wall,
+            "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "i8 x3 limbs (i32 accumulate)" if args.mode == "fast" else "f32",
+            "data": "synthetic",
+            "config": {"workload": "config 2: %d utterances x %d frames x D=%d binary features, "
+                                   "%d-template bank, L=%d, per GPU; max-score + template id per frame"
+                                   % (CFG["N"], CFG["T"], CFG["F"] * CFG["E"], CFG["M"], CFG["L"]),
+                       "mode": args.mode, "frames_per_gpu": frames, "parallelism": "utterance-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms_per_launch": per_launch_s * 1e3,
+                         "alg_bytes_per_launch": alg_bytes},
+            "compute": {"alg_tflops": alg_flops / per_launch_s / 1e12,
+                        "peak": MFMA_I8_PEAK_TOPS if args.mode == "fast" else VALU_F32_PEAK_TFLOPS,
+                        "unit": "TOP/s (int8 MFMA, dense)" if args.mode == "fast" else "TFLOP/s (f32 VALU)",
+                        "note": "algorithmic flops = 2*D*sum(L_m) per valid window (SURVEY 8(d)); "
+                                "the int8 path spends 3 limb-MACs per algorithmic MAC"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(corpus)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        ctx.dist_finalize()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,172 @@
+/*
+ * tsr.h -- C ABI of libtsr_hip.so, the MI355X (gfx950) implementation of the
+ * sliding-window template-scoring path of markstoehr/Template-Speech-Recognition.
+ *
+ * The reference exposes this path as three Cython extension modules
+ * (template_speech_rec/setup.py:35-41); there is no C interface to match, so
+ * this header declares one entry point per reference function, with plain
+ * pointers + sizes (no Python, NumPy or torch types).  The Python modules in
+ * template-speech-recognition_amd/template_speech_rec/ bind these with ctypes
+ * under the reference's own module and function names.
+ *
+ * Conventions
+ *   - every function returns an int status (TSR_OK == 0); tsr_strerror() names
+ *     it, tsr_last_error() gives the detailed message of the calling thread;
+ *   - all host arrays are C-contiguous; the reference's trailing (frequency,
+ *     part) axes are passed flattened as one feature axis D (the reference
+ *     iterates frequency-outer, part-inner == flattened order);
+ *   - inputs are borrowed and never modified (except tsr_spread_graph_patches,
+ *     which mutates in place like code_parts.pyx:459-503); outputs are written
+ *     to caller-allocated host buffers unless the name says `_device`;
+ *   - a tsr_ctx owns one device, one HIP stream and its scratch buffers; it is
+ *     not thread-safe: use one ctx per host thread / per GPU;
+ *   - nothing here falls back to a CPU path: without a GPU every compute call
+ *     fails with TSR_ERR_NO_DEVICE.
+ */
+#ifndef TSR_H
+#define TSR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSR_VERSION 100 /* 0.1.0 */
+
+enum {
+    TSR_OK = 0,
+    TSR_ERR_INVALID = 1,     /* bad shape / null pointer / size out of range      */
+    TSR_ERR_HIP = 2,         /* a HIP runtime call failed (see tsr_last_error)    */
+    TSR_ERR_NO_DEVICE = 3,   /* no usable gfx950 device                           */
+    TSR_ERR_UNSUPPORTED = 4, /* valid request this build cannot serve             */
+    TSR_ERR_NONFINITE = 5,   /* filter bank contains inf/nan                      */
+    TSR_ERR_RCCL = 6         /* an RCCL call failed or librccl is unavailable     */
+};
+
+/* Scoring precision/algorithm selector (`flags` of the bank scorers).
+ *   TSR_EXACT: f32 accumulation in the reference's order tau -> f -> k
+ *              (compute_likelihood_linear_filter.pyx:162-175); raw scores are
+ *              bit-identical to the Cython path.
+ *   TSR_FAST : MFMA path.  The bank is held as three int8 limbs of a 24-bit
+ *              fixed-point encoding (per-template power-of-two scale) and
+ *              accumulated exactly in int32; the only error is the weight
+ *              quantisation (<= 2^-24 * max|W_m| per tap), far inside the 1e-4
+ *              relative parity bar and independent of summation order.
+ *   TSR_TRUNCATE: windows overhanging the end of an utterance keep their
+ *              partial sum instead of the reference's 0 (the
+ *              get_max_detect_examples convention, :58-59).  OR-able. */
+enum { TSR_EXACT = 0, TSR_FAST = 1, TSR_TRUNCATE = 16 };
+
+typedef struct tsr_ctx tsr_ctx;       /* device + stream + scratch                 */
+typedef struct tsr_bank tsr_bank;     /* device-resident template bank             */
+typedef struct tsr_corpus tsr_corpus; /* device-resident utterances + their scores */
+typedef struct tsr_parts tsr_parts;   /* device-resident part models (front-end)   */
+
+/* ---- library / context ---------------------------------------------------- */
+int tsr_version(void);
+const char *tsr_strerror(int status);
+const char *tsr_last_error(void);
+int tsr_device_count(int *count);
+int tsr_ctx_create(int device, tsr_ctx **out);
+int tsr_ctx_destroy(tsr_ctx *ctx);
+int tsr_ctx_sync(tsr_ctx *ctx);
+/* hipEvent pair on the ctx stream: kernel time of everything enqueued between. */
+int tsr_timer_start(tsr_ctx *ctx);
+int tsr_timer_stop(tsr_ctx *ctx, float *elapsed_ms);
+/* device name, CU count, HBM bytes (for bench/DESIGN reporting) */
+int tsr_device_info(tsr_ctx *ctx, char *name, int name_len, int *cus, int64_t *hbm_bytes);
+
+/* ---- compute_likelihood_linear_filter.pyx, one utterance, one filter -------- */
+/* detect(F, LF)            compute_likelihood_linear_filter.pyx:135-176
+ * F u8 [T,D], LF f32 [L,D] -> out f32 [T]; out[t] = 0 for t > T-L.  T < L is
+ * TSR_ERR_INVALID (the reference wraps a uint16 at :157 and reads out of bounds). */
+int tsr_detect_u8(tsr_ctx *ctx, const uint8_t *F, int64_t T, int64_t D, const float *LF, int64_t L,
+                  float *out);
+/* detect_float / detect_float2d / detect_spectral   :178-219, :281-318, :322-359 */
+int tsr_detect_f32(tsr_ctx *ctx, const float *F, int64_t T, int64_t D, const float *LF, int64_t L,
+                   float *out);
+/* detect_float_max(F, LF, cs)   :221-278.  LF f32 [M,L,D], cs f32 [M] ->
+ * out f32 [T], ids u16 [T] (first maximum; zeros for t > T-L). */
+int tsr_detect_f32_max(tsr_ctx *ctx, const float *F, int64_t T, int64_t D, const float *LF,
+                       int64_t M, int64_t L, const float *cs, float *out, uint16_t *ids);
+/* get_max_detect_examples(F, LF, lengths)   :21-76.  F u8 [N,T,D], LF f64 [L,D],
+ * lengths i64 [N] -> out f64 [N] (filter truncated at the example end). */
+int tsr_max_detect_examples_u8(tsr_ctx *ctx, const uint8_t *F, int64_t N, int64_t T, int64_t D,
+                               const double *LF, int64_t L, const int64_t *lengths, double *out);
+
+/* ---- template bank: get_train_data.py:962-992 (_compute_detection_E) --------- */
+/* W_cat: template m is L[m]*D floats, templates concatenated in order; c f64 [M]
+ * (estimate_template.py:230-251 produces exactly (W_m f32, c_m f64)). */
+int tsr_bank_create(tsr_ctx *ctx, const float *W_cat, const int32_t *L, const double *c, int32_t M,
+                    int64_t D, tsr_bank **out);
+int tsr_bank_destroy(tsr_bank *bank);
+int tsr_bank_info(const tsr_bank *bank, int32_t *M, int64_t *D, int32_t *Lmax, int64_t *sumL);
+
+/* Score utterances against the bank: scores[p] = max_m (detect(E_n, W_m)[t] +
+ * f32(c_m)), ids[p] = lowest m attaining it, p = frame_offsets[n] + t.
+ * feats u8 [sum T_n, D] (utterance n = frames [frame_offsets[n],
+ * frame_offsets[n+1])), frame_offsets i64 [N+1].  Positions t > T_n - L_m score
+ * 0 + c_m exactly as the reference's zero tail does (quirk: they take part in
+ * the max).  T_n < L_m is allowed here: every frame is then tail for m. */
+int tsr_score_bank_u8(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *feats,
+                      const int64_t *frame_offsets, int64_t N, int flags, float *scores,
+                      int32_t *ids);
+/* Same, but every template's score: per_template f32 [M, sum T_n]. */
+int tsr_score_bank_all_u8(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *feats,
+                          const int64_t *frame_offsets, int64_t N, int flags, float *per_template);
+
+/* Device-resident steady state (what bench.py times): upload once, score many
+ * times with inputs and outputs staying in HBM, download on demand. */
+int tsr_corpus_create(tsr_ctx *ctx, const uint8_t *feats, const int64_t *frame_offsets, int64_t N,
+                      int64_t D, tsr_corpus **out);
+int tsr_corpus_destroy(tsr_corpus *corpus);
+int tsr_corpus_score(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *corpus, int flags); /* async */
+int tsr_corpus_download(tsr_ctx *ctx, const tsr_corpus *corpus, float *scores, int32_t *ids);
+int tsr_corpus_frames(const tsr_corpus *corpus, int64_t *total_frames);
+
+/* ---- code_parts.pyx / spread_waliji_patches.pyx ------------------------------- */
+/* code_parts (fast=0, code_parts.pyx:70-135) / code_parts_fast (fast=1, :247-295).
+ * X u8 [X0,X1,E]; log_parts, log_invparts f64 [K,P0,P1,E]; out f64
+ * [X0-P0+1, X1-P1+1, K+1].  `threshold` is compared as unsigned like the
+ * generated C does, so a negative threshold makes every location background. */
+int tsr_code_parts(tsr_ctx *ctx, const uint8_t *X, int64_t X0, int64_t X1, int64_t E,
+                   const double *log_parts, const double *log_invparts, int64_t K, int64_t P0,
+                   int64_t P1, int threshold, int fast, double *out);
+/* spread_patches (code_parts.pyx:406-457) == spread_waliji_patches
+ * (spread_waliji_patches.pyx:15-59).  X i64 [X0,X1] -> out u8 [X0,X1,K]. */
+int tsr_spread_patches(tsr_ctx *ctx, const int64_t *X, int64_t X0, int64_t X1, int r0, int r1,
+                       int64_t K, uint8_t *out);
+/* spread_graph_patches (code_parts.pyx:459-503): X u8 [X0,X1,K] updated in
+ * place, graph u8 [K,K]; sequential over the source part like the reference. */
+int tsr_spread_graph_patches(tsr_ctx *ctx, uint8_t *X, int64_t X0, int64_t X1, int64_t K,
+                             const uint8_t *graph);
+
+/* Fused front-end, get_train_data.py:2619-2628 (get_part_features) and :183-191
+ * (get_waliji_feature_map): code_parts[_fast] -> argmax (first max) ->
+ * spread(r0,r1) -> [graph closure] -> [::g0, ::g1] without the f64 map ever
+ * leaving the chip.  out u8 [ceil(N0/g0), ceil(N1/g1), K], N0 = X0-P0+1,
+ * N1 = X1-P1+1; argmax_out (optional, may be NULL) i64 [N0,N1]. */
+int tsr_parts_create(tsr_ctx *ctx, const double *log_parts, const double *log_invparts, int64_t K,
+                     int64_t P0, int64_t P1, int64_t E, tsr_parts **out);
+int tsr_parts_destroy(tsr_parts *parts);
+int tsr_part_features(tsr_ctx *ctx, const tsr_parts *parts, const uint8_t *X, int64_t X0,
+                      int64_t X1, int threshold, int fast, int r0, int r1, const uint8_t *graph,
+                      int g0, int g1, uint8_t *out, int64_t *argmax_out);
+
+/* ---- multi-GPU: utterances shard across ranks, the bank is broadcast once ----- */
+/* One process per GPU.  Rank 0 calls tsr_dist_unique_id and hands the 128 bytes
+ * to the other ranks over any host channel; every rank then calls
+ * tsr_dist_init.  tsr_bank_broadcast replaces the contents of `bank` on every
+ * rank with rank `root`'s (an ncclBroadcast over xGMI of the device-resident
+ * bank buffers); all ranks must have created a bank of identical geometry.
+ * No other collective exists on this path: scoring needs no cross-GPU exchange. */
+int tsr_dist_unique_id(char id[128]);
+int tsr_dist_init(tsr_ctx *ctx, const char id[128], int nranks, int rank);
+int tsr_dist_finalize(tsr_ctx *ctx);
+int tsr_bank_broadcast(tsr_ctx *ctx, tsr_bank *bank, int root);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSR_H */

@@ -1,0 +1,294 @@
+// detect_exact.hip -- sequential-order (bit-exact) scoring kernels for gfx950.
+//
+// The reference accumulates every window's score in f32, one tap at a time, in
+// the order tau -> frequency -> part (compute_likelihood_linear_filter.pyx:162-175).
+// Floating-point addition is not associative, so the only way to reproduce its
+// bits is to keep that order.  These kernels give every lane one window and walk
+// the taps in reference order; parallelism comes from the windows (one lane
+// each) and the templates (TSR_MG accumulators per lane), never from splitting a
+// sum.  `acc = fma(x, w, acc)` with x in {0.0f, 1.0f} and finite w is exactly
+// the reference's `if F: acc += w` (x == 1: rn(acc + w); x == 0: acc).
+//
+// Roofline: VALU-bound (one v_fmac per tap and template).  Algorithmic work is
+// P * Lmax * D * M fused adds; HBM traffic is the feature map once plus
+// 4*M bytes per frame of raw scores.
+#include "tsr_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ uint32_t normalise01(uint32_t x)
+{
+    // byte-wise (b != 0) ? 1 : 0 without cross-byte carries
+    return ((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) >> 7) & 0x01010101u;
+}
+
+// One block = TB consecutive frame positions x (256/TB) template groups.
+// LDS holds rows [p0 + tau0, p0 + tau0 + TB + TC - 1) of the (0/1-normalised)
+// feature map, SD dwords per row (SD odd => conflict-free stride across lanes).
+template <int TB>
+__global__ __launch_bounds__(kThreads) void exact_bank_kernel(
+    const uint8_t *__restrict__ X, int64_t P, int D, int Dq, int SD, int TC,
+    const float *__restrict__ Wx, const int64_t *__restrict__ gx_off,
+    const int32_t *__restrict__ gx_L, int n_groups, int M, float *__restrict__ raw)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    constexpr int GPB = kThreads / TB;  // template groups per block
+    const int tid = threadIdx.x;
+    const int pos = tid % TB;
+    // wave-uniform (TB is a multiple of 64); readfirstlane makes that provable so that
+    // the weight lines below are fetched with scalar loads into SGPRs
+    const int g = blockIdx.y * GPB + __builtin_amdgcn_readfirstlane(tid / TB);
+    const int64_t p0 = (int64_t)blockIdx.x * TB;
+    const bool active = g < n_groups;
+    const int Lg = active ? gx_L[g] : 0;
+    const float *__restrict__ Wg = Wx + (active ? gx_off[g] : 0);
+
+    int Lblk = 0;  // longest template over the groups of this block
+    for (int k = 0; k < GPB; ++k) {
+        int gg = blockIdx.y * GPB + k;
+        if (gg < n_groups) Lblk = max(Lblk, gx_L[gg]);
+    }
+
+    float acc[TSR_MG];
+#pragma unroll
+    for (int m = 0; m < TSR_MG; ++m) acc[m] = 0.0f;
+
+    const int rows = TB + TC - 1;
+    const bool aligned = (D % 4) == 0;
+    for (int tau0 = 0; tau0 < Lblk; tau0 += TC) {
+        __syncthreads();
+        // ---- stage rows [p0+tau0, p0+tau0+rows) -------------------------------
+        for (int idx = tid; idx < rows * SD; idx += kThreads) {
+            const int r = idx / SD, i = idx - r * SD;
+            const int64_t p = p0 + tau0 + r;
+            uint32_t v = 0;
+            if (p < P && i < Dq) {
+                const int64_t byte0 = p * D + 4 * (int64_t)i;
+                if (aligned) {
+                    v = *reinterpret_cast<const uint32_t *>(X + byte0);
+                } else {
+                    const int nb = min(4, D - 4 * i);
+                    for (int b = 0; b < nb; ++b) v |= (uint32_t)X[byte0 + b] << (8 * b);
+                }
+                v = normalise01(v);
+            }
+            lds[idx] = v;
+        }
+        __syncthreads();
+        // ---- accumulate taps tau0 .. min(tau0+TC, Lg) in reference order ---------
+        const int tau1 = min(tau0 + TC, Lg);
+        for (int tau = tau0; tau < tau1; ++tau) {
+            const uint32_t *xr = lds + (pos + (tau - tau0)) * SD;
+            const float *__restrict__ w = Wg + (int64_t)tau * Dq * (TSR_MG * 4);
+#pragma unroll 2
+            for (int i = 0; i < Dq; ++i) {
+                const uint32_t x = xr[i];
+                const float x0 = (float)(x & 0xffu), x1 = (float)((x >> 8) & 0xffu),
+                            x2 = (float)((x >> 16) & 0xffu), x3 = (float)(x >> 24);
+                const float *__restrict__ wi = w + i * (TSR_MG * 4);
+#pragma unroll
+                for (int m = 0; m < TSR_MG; ++m) {
+                    acc[m] = __builtin_fmaf(x0, wi[4 * m + 0], acc[m]);
+                    acc[m] = __builtin_fmaf(x1, wi[4 * m + 1], acc[m]);
+                    acc[m] = __builtin_fmaf(x2, wi[4 * m + 2], acc[m]);
+                    acc[m] = __builtin_fmaf(x3, wi[4 * m + 3], acc[m]);
+                }
+            }
+        }
+    }
+    const int64_t p = p0 + pos;
+    if (active && p < P) {
+#pragma unroll
+        for (int m = 0; m < TSR_MG; ++m) {
+            const int mm = g * TSR_MG + m;
+            if (mm < M) raw[(int64_t)mm * P + p] = acc[m];
+        }
+    }
+}
+
+// Fallback for feature rows too wide for the LDS tile: same order, rows read
+// straight from global memory (L1/L2 absorb the window overlap).
+__global__ __launch_bounds__(kThreads) void exact_bank_direct_kernel(
+    const uint8_t *__restrict__ X, int64_t P, int D, int Dq, const float *__restrict__ Wx,
+    const int64_t *__restrict__ gx_off, const int32_t *__restrict__ gx_L, int M,
+    float *__restrict__ raw)
+{
+    const int g = blockIdx.y;
+    const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int Lg = gx_L[g];
+    const float *__restrict__ Wg = Wx + gx_off[g];
+    float acc[TSR_MG];
+#pragma unroll
+    for (int m = 0; m < TSR_MG; ++m) acc[m] = 0.0f;
+    for (int tau = 0; tau < Lg; ++tau) {
+        const int64_t row = p + tau;
+        const float *__restrict__ w = Wg + (int64_t)tau * Dq * (TSR_MG * 4);
+        for (int d = 0; d < D; ++d) {
+            const float x = (row < P && X[row * D + d]) ? 1.0f : 0.0f;
+            const float *__restrict__ wi = w + (d >> 2) * (TSR_MG * 4) + (d & 3);
+#pragma unroll
+            for (int m = 0; m < TSR_MG; ++m) acc[m] = __builtin_fmaf(x, wi[4 * m], acc[m]);
+        }
+    }
+    if (p < P) {
+#pragma unroll
+        for (int m = 0; m < TSR_MG; ++m) {
+            const int mm = g * TSR_MG + m;
+            if (mm < M) raw[(int64_t)mm * P + p] = acc[m];
+        }
+    }
+}
+
+// get_train_data.py:962-992: v = raw (0 on the tail t > T - L_m) + f32(c_m);
+// running max with strict '>' (lowest template id wins ties).
+__global__ __launch_bounds__(kThreads) void bank_epilogue_kernel(
+    const float *__restrict__ raw, int64_t P, int M, const int32_t *__restrict__ L,
+    const float *__restrict__ cf, const int32_t *__restrict__ utt_end, float *__restrict__ scores,
+    int32_t *__restrict__ ids, float *__restrict__ all)
+{
+    const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (p >= P) return;
+    const int64_t end = utt_end[p];
+    float best = 0.0f;
+    int besti = 0;
+    for (int m = 0; m < M; ++m) {
+        const float r = (p + L[m] <= end) ? raw[(int64_t)m * P + p] : 0.0f;
+        const float v = r + cf[m];
+        if (all) all[(int64_t)m * P + p] = v;
+        if (m == 0 || v > best) {
+            best = v;
+            besti = m;
+        }
+    }
+    if (scores) scores[p] = best;
+    if (ids) ids[p] = besti;
+}
+
+// compute_likelihood_linear_filter.pyx:178-219 / :221-278 / :281-359: f32
+// features, product rounded to f32 then added (no FMA contraction), accumulator
+// initialised to cs[m] when given.  One thread per (template, window).
+__global__ __launch_bounds__(kThreads) void detect_f32_kernel(
+    const float *__restrict__ F, int T, int D, const float *__restrict__ LF, int M, int L,
+    const float *__restrict__ cs, float *__restrict__ out)
+{
+#pragma clang fp contract(off)  // the reference rounds the product to f32 before the add
+    const int t = blockIdx.x * kThreads + threadIdx.x;
+    const int m = blockIdx.y;
+    if (t >= T) return;
+    float acc = 0.0f;
+    if (t + L <= T) {
+        acc = cs ? cs[m] : 0.0f;
+        const float *__restrict__ w = LF + (int64_t)m * L * D;
+        const float *__restrict__ f = F + (int64_t)t * D;
+        for (int k = 0; k < L * D; ++k) {
+            const float prod = w[k] * f[k];
+            acc = acc + prod;
+        }
+    }
+    out[(int64_t)m * T + t] = acc;
+}
+
+// compute_likelihood_linear_filter.pyx:21-76: f64 sum, filter truncated at the
+// end of the example.  One thread per (example, t); the max over t is taken by
+// the caller with the reference's first-t/strict-'>' rule.
+__global__ __launch_bounds__(kThreads) void max_detect_examples_kernel(
+    const uint8_t *__restrict__ F, int N, int T, int D, const double *__restrict__ LF, int L,
+    double *__restrict__ tmp)
+{
+    const int t = blockIdx.x * kThreads + threadIdx.x;
+    const int n = blockIdx.y;
+    if (t >= T) return;
+    const int mt = min(T - t, L);
+    const uint8_t *__restrict__ f = F + ((int64_t)n * T + t) * D;
+    double acc = 0.0;
+    for (int k = 0; k < mt * D; ++k)
+        if (f[k]) acc += LF[k];
+    tmp[(int64_t)n * T + t] = acc;
+}
+
+}  // namespace
+
+int tsr_launch_exact_bank(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *d_feats, int64_t P,
+                          float *d_raw)
+{
+    if (P == 0) return TSR_OK;
+    const int Dq = bank->Dq;
+    const int SD = Dq | 1;
+    const int Lmax = bank->Lmax;
+    const int64_t *d_gx_off = bank->d_gx_off;
+    const int32_t *d_gx_L = bank->d_gx_L;
+    const size_t row_bytes = (size_t)SD * 4;
+    const size_t pref = 64 * 1024, cap = 150 * 1024;
+    int TB = 0, TC = 0;
+    if (pref / row_bytes >= 128 + 1) {
+        TB = 128;
+        TC = (int)std::min<size_t>(Lmax, pref / row_bytes - 127);
+    } else if (cap / row_bytes >= 64 + 1) {
+        TB = 64;
+        TC = (int)std::min<size_t>(Lmax, cap / row_bytes - 63);
+    }
+    if (TB == 0) {
+        dim3 grid((unsigned)((P + kThreads - 1) / kThreads), bank->n_groups);
+        hipLaunchKernelGGL(exact_bank_direct_kernel, grid, dim3(kThreads), 0, ctx->stream, d_feats, P,
+                           (int)bank->D, Dq, bank->d_Wx, d_gx_off, d_gx_L, bank->M, d_raw);
+        TSR_HIP(hipGetLastError());
+        return TSR_OK;
+    }
+    const size_t lds = (size_t)(TB + TC - 1) * row_bytes;
+    const int GPB = kThreads / TB;
+    dim3 grid((unsigned)((P + TB - 1) / TB), (bank->n_groups + GPB - 1) / GPB);
+    if (TB == 128) {
+        TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(exact_bank_kernel<128>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(exact_bank_kernel<128>, grid, dim3(kThreads), lds, ctx->stream, d_feats, P,
+                           (int)bank->D, Dq, SD, TC, bank->d_Wx, d_gx_off, d_gx_L, bank->n_groups,
+                           bank->M, d_raw);
+    } else {
+        TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(exact_bank_kernel<64>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(exact_bank_kernel<64>, grid, dim3(kThreads), lds, ctx->stream, d_feats, P,
+                           (int)bank->D, Dq, SD, TC, bank->d_Wx, d_gx_off, d_gx_L, bank->n_groups,
+                           bank->M, d_raw);
+    }
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+
+int tsr_launch_bank_epilogue(tsr_ctx *ctx, const tsr_bank *bank, const float *d_raw, int64_t P,
+                             const int32_t *d_utt_end, int flags, float *d_scores, int32_t *d_ids,
+                             float *d_all)
+{
+    (void)flags;
+    if (P == 0) return TSR_OK;
+    hipLaunchKernelGGL(bank_epilogue_kernel, dim3((unsigned)((P + kThreads - 1) / kThreads)),
+                       dim3(kThreads), 0, ctx->stream, d_raw, P, bank->M, bank->d_L, bank->d_cf,
+                       d_utt_end, d_scores, d_ids, d_all);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+
+int tsr_launch_detect_f32(tsr_ctx *ctx, const float *d_F, int64_t T, int64_t D, const float *d_LF,
+                          int64_t M, int64_t L, const float *d_cs, float *d_out, uint16_t *d_ids)
+{
+    (void)d_ids;
+    dim3 grid((unsigned)((T + kThreads - 1) / kThreads), (unsigned)M);
+    hipLaunchKernelGGL(detect_f32_kernel, grid, dim3(kThreads), 0, ctx->stream, d_F, (int)T, (int)D,
+                       d_LF, (int)M, (int)L, d_cs, d_out);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+
+int tsr_launch_max_detect_examples(tsr_ctx *ctx, const uint8_t *d_F, int64_t N, int64_t T,
+                                   int64_t D, const double *d_LF, int64_t L,
+                                   const int64_t *d_lengths, double *d_tmp, double *d_out)
+{
+    (void)d_lengths;
+    (void)d_out;
+    dim3 grid((unsigned)((T + kThreads - 1) / kThreads), (unsigned)N);
+    hipLaunchKernelGGL(max_detect_examples_kernel, grid, dim3(kThreads), 0, ctx->stream, d_F, (int)N,
+                       (int)T, (int)D, d_LF, (int)L, d_tmp);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}

@@ -1,0 +1,175 @@
+// parts.hip -- the parts-coding front-end on gfx950:
+//   code_parts / code_parts_fast  (code_parts.pyx:70-135, :247-295)
+//   np.argmax(out, -1)            (get_train_data.py:2621, :184)
+//   spread_patches == spread_waliji_patches (code_parts.pyx:406-457,
+//                                            spread_waliji_patches.pyx:15-59)
+//   spread_graph_patches          (code_parts.pyx:459-503)
+//
+// code_parts: one lane per patch location.  For part k the reference adds, in
+// the order i -> j -> z over the P0 x P1 x E patch, either log_parts[k,i,j,z]
+// (edge present) or log_invparts[k,i,j,z] -- a sequential f64 sum per (location,
+// part).  We keep that order per part (bit-identical f64 results, hence an
+// identical argmax) and take the parallelism from locations (lanes) and parts
+// (KC independent accumulators per lane).  The two tables are interleaved in
+// LDS as [q][k][{inv, part}] so that the lane's edge bit selects the operand by
+// ADDRESS (one ds_read_b64, lanes hit one of two adjacent 8-byte slots: a
+// broadcast, conflict-free) instead of by v_cndmask on a 64-bit value.
+#include "tsr_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int KC = 16;   // parts per pass (accumulators per lane)
+constexpr int QC = 128;  // patch cells per LDS table chunk: QC*KC*16 B = 32 KiB
+
+__global__ __launch_bounds__(kThreads) void code_parts_kernel(
+    const uint8_t *__restrict__ X, int X0, int X1, int E, int P0, int P1,
+    const double *__restrict__ tab /*[Q][K][2]*/, int K, unsigned threshold, int fast,
+    double *__restrict__ out /*[N0*N1][K+1] or null*/, int32_t *__restrict__ argmax /*or null*/)
+{
+    __shared__ __attribute__((aligned(16))) double lt[QC * KC * 2];
+    const int N0 = X0 - P0 + 1, N1 = X1 - P1 + 1;
+    const int Q = P0 * P1 * E;
+    const int64_t loc = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const bool live = loc < (int64_t)N0 * N1;
+    const int i0 = live ? (int)(loc / N1) : 0;
+    const int j0 = live ? (int)(loc - (int64_t)i0 * N1) : 0;
+
+    unsigned count = 0;
+    double slot0 = 0.0;       // code_parts_fast: sum_k (out[k+1] - 1), k ascending
+    double bestv = 0.0;       // first maximum over the part slots
+    int bestk = -1;
+
+    for (int kc0 = 0; kc0 < K; kc0 += KC) {
+        double acc[KC];
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) acc[kk] = 0.0;
+        for (int qc0 = 0; qc0 < Q; qc0 += QC) {
+            const int nq = min(QC, Q - qc0);
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < nq * KC * 2; idx += kThreads) {
+                const int q = idx / (KC * 2), r = idx - q * (KC * 2);
+                const int kk = r >> 1, sel = r & 1;
+                const int k = kc0 + kk;
+                lt[idx] = (k < K) ? tab[((int64_t)(qc0 + q) * K + k) * 2 + sel] : 0.0;
+            }
+            __syncthreads();
+            if (live) {
+                for (int q = 0; q < nq; ++q) {
+                    const int qq = qc0 + q;
+                    const int z = qq % E, ij = qq / E;
+                    const int j = ij % P1, i = ij / P1;
+                    const unsigned x = X[((int64_t)(i0 + i) * X1 + (j0 + j)) * E + z] ? 1u : 0u;
+                    if (kc0 == 0) count += x;
+                    const double *row = lt + q * (KC * 2) + x;
+#pragma unroll
+                    for (int kk = 0; kk < KC; ++kk) acc[kk] += row[2 * kk];
+                }
+            }
+        }
+        // count is complete after the first pass over q (kc0 == 0), i.e. here.
+        const bool coded = count >= threshold;
+        if (live) {
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk) {
+                const int k = kc0 + kk;
+                if (k < K) {
+                    const double v = coded ? acc[kk] : 0.0;
+                    if (out) out[loc * (K + 1) + k + 1] = v;
+                    if (coded) {
+                        slot0 += v - 1.0;
+                        if (bestk < 0 || v > bestv) {
+                            bestv = v;
+                            bestk = k;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (!live) return;
+    const bool coded = count >= threshold;
+    double s0;
+    if (fast)
+        s0 = coded ? slot0 : 1.0;
+    else
+        s0 = coded ? -__builtin_inf() : 0.0;
+    if (out) out[loc * (K + 1)] = s0;
+    if (argmax) argmax[loc] = (coded && bestk >= 0 && bestv > s0) ? bestk + 1 : 0;
+}
+
+// One thread per (sub-sampled) output location: dilate the part-id map over the
+// clipped (2*r0+1) x (2*r1+1) box.  out rows must be zeroed beforehand.
+__global__ __launch_bounds__(kThreads) void spread_kernel(const int32_t *__restrict__ A, int X0,
+                                                          int X1, int r0, int r1, int K, int g0,
+                                                          int g1, int O0, int O1,
+                                                          uint8_t *__restrict__ out)
+{
+    const int64_t o = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (o >= (int64_t)O0 * O1) return;
+    const int oi = (int)(o / O1), oj = (int)(o - (int64_t)oi * O1);
+    const int i = oi * g0, j = oj * g1;
+    const int lo0 = max(i - r0, 0), hi0 = min(i + r0 + 1, X0);
+    const int lo1 = max(j - r1, 0), hi1 = min(j + r1 + 1, X1);
+    uint8_t *row = out + o * K;
+    for (int x0 = lo0; x0 < hi0; ++x0)
+        for (int x1 = lo1; x1 < hi1; ++x1) {
+            const int p = A[(int64_t)x0 * X1 + x1];
+            if (p > 0) row[p - 1] = 1;
+        }
+}
+
+// In place, one thread per location, sequential over the source part so that a
+// part switched on earlier in the scan propagates further (reference order).
+__global__ __launch_bounds__(kThreads) void spread_graph_kernel(uint8_t *__restrict__ X,
+                                                                int64_t n_loc, int K,
+                                                                const uint8_t *__restrict__ graph)
+{
+    const int64_t o = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (o >= n_loc) return;
+    uint8_t *x = X + o * K;
+    for (int a = 0; a < K; ++a)
+        if (x[a] > 0)
+            for (int b = 0; b < K; ++b)
+                if (graph[a * K + b]) x[b] = 1;
+}
+
+}  // namespace
+
+int tsr_launch_code_parts(tsr_ctx *ctx, const tsr_parts *parts, const uint8_t *d_X, int64_t X0,
+                          int64_t X1, int threshold, int fast, double *d_out, int32_t *d_argmax)
+{
+    const int64_t n_loc = (X0 - parts->P0 + 1) * (X1 - parts->P1 + 1);
+    if (n_loc <= 0) return TSR_OK;
+    hipLaunchKernelGGL(code_parts_kernel, dim3((unsigned)((n_loc + kThreads - 1) / kThreads)),
+                       dim3(kThreads), 0, ctx->stream, d_X, (int)X0, (int)X1, (int)parts->E,
+                       (int)parts->P0, (int)parts->P1, parts->d_tab, (int)parts->K,
+                       (unsigned)threshold, fast, d_out, d_argmax);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+
+int tsr_launch_spread(tsr_ctx *ctx, const int32_t *d_A, int64_t X0, int64_t X1, int r0, int r1,
+                      int64_t K, int g0, int g1, const uint8_t *d_graph, uint8_t *d_out)
+{
+    const int64_t O0 = (X0 + g0 - 1) / g0, O1 = (X1 + g1 - 1) / g1;
+    const int64_t n = O0 * O1;
+    if (n <= 0 || K <= 0) return TSR_OK;
+    TSR_HIP(hipMemsetAsync(d_out, 0, (size_t)(n * K), ctx->stream));
+    hipLaunchKernelGGL(spread_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads),
+                       0, ctx->stream, d_A, (int)X0, (int)X1, r0, r1, (int)K, g0, g1, (int)O0,
+                       (int)O1, d_out);
+    TSR_HIP(hipGetLastError());
+    if (d_graph) TSR_TRY(tsr_launch_spread_graph(ctx, d_out, n, K, d_graph));
+    return TSR_OK;
+}
+
+int tsr_launch_spread_graph(tsr_ctx *ctx, uint8_t *d_X, int64_t n_loc, int64_t K,
+                            const uint8_t *d_graph)
+{
+    if (n_loc <= 0 || K <= 0) return TSR_OK;
+    hipLaunchKernelGGL(spread_graph_kernel, dim3((unsigned)((n_loc + kThreads - 1) / kThreads)),
+                       dim3(kThreads), 0, ctx->stream, d_X, n_loc, (int)K, d_graph);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}

@@ -1,0 +1,815 @@
+// tsr_api.hip -- the C ABI of libtsr_hip.so (declared in include/tsr.h).
+// Host-side validation, device buffer ownership, and kernel sequencing.  All
+// arithmetic lives in detect_exact.hip / detect_mfma.hip / parts.hip.
+#include <dlfcn.h>
+#include <math.h>
+#include <stdarg.h>
+
+#include <algorithm>
+#include <new>
+
+#include "tsr_internal.h"
+
+// ---- errors ---------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void tsr_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+TSR_API int tsr_version(void) { return TSR_VERSION; }
+
+TSR_API const char *tsr_last_error(void) { return g_err; }
+
+TSR_API const char *tsr_strerror(int status)
+{
+    switch (status) {
+    case TSR_OK: return "ok";
+    case TSR_ERR_INVALID: return "invalid argument";
+    case TSR_ERR_HIP: return "HIP runtime error";
+    case TSR_ERR_NO_DEVICE: return "no usable GPU device";
+    case TSR_ERR_UNSUPPORTED: return "unsupported request";
+    case TSR_ERR_NONFINITE: return "non-finite filter value";
+    case TSR_ERR_RCCL: return "RCCL error";
+    default: return "unknown status";
+    }
+}
+
+// ---- context ---------------------------------------------------------------------
+TSR_API int tsr_device_count(int *count)
+{
+    TSR_REQUIRE(count, "tsr_device_count: null pointer");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return TSR_OK;
+}
+
+TSR_API int tsr_ctx_create(int device, tsr_ctx **out)
+{
+    TSR_REQUIRE(out, "tsr_ctx_create: null out pointer");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        tsr_set_error("tsr_ctx_create: no HIP device is visible (this library has no CPU path)");
+        return TSR_ERR_NO_DEVICE;
+    }
+    TSR_REQUIRE(device >= 0 && device < n, "tsr_ctx_create: device %d out of range [0,%d)", device, n);
+    TSR_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    TSR_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        tsr_set_error("tsr_ctx_create: device %d is %s; this library is built for gfx950 only", device,
+                      prop.gcnArchName);
+        return TSR_ERR_NO_DEVICE;
+    }
+    tsr_ctx *ctx = new (std::nothrow) tsr_ctx;
+    TSR_REQUIRE(ctx, "tsr_ctx_create: out of host memory");
+    ctx->device = device;
+    ctx->cus = prop.multiProcessorCount;
+    ctx->hbm_bytes = (int64_t)prop.totalGlobalMem;
+    snprintf(ctx->name, sizeof ctx->name, "%s (%s)", prop.name, prop.gcnArchName);
+    TSR_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    TSR_HIP(hipEventCreate(&ctx->ev0));
+    TSR_HIP(hipEventCreate(&ctx->ev1));
+    *out = ctx;
+    return TSR_OK;
+}
+
+TSR_API int tsr_ctx_destroy(tsr_ctx *ctx)
+{
+    if (!ctx) return TSR_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm) tsr_dist_finalize(ctx);
+    for (auto &b : ctx->scratch)
+        if (b.ptr) (void)hipFree(b.ptr);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return TSR_OK;
+}
+
+TSR_API int tsr_ctx_sync(tsr_ctx *ctx)
+{
+    TSR_REQUIRE(ctx, "tsr_ctx_sync: null ctx");
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    return TSR_OK;
+}
+
+TSR_API int tsr_timer_start(tsr_ctx *ctx)
+{
+    TSR_REQUIRE(ctx, "tsr_timer_start: null ctx");
+    TSR_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    return TSR_OK;
+}
+
+TSR_API int tsr_timer_stop(tsr_ctx *ctx, float *elapsed_ms)
+{
+    TSR_REQUIRE(ctx && elapsed_ms, "tsr_timer_stop: null pointer");
+    TSR_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    TSR_HIP(hipEventSynchronize(ctx->ev1));
+    TSR_HIP(hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return TSR_OK;
+}
+
+TSR_API int tsr_device_info(tsr_ctx *ctx, char *name, int name_len, int *cus, int64_t *hbm_bytes)
+{
+    TSR_REQUIRE(ctx, "tsr_device_info: null ctx");
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s", ctx->name);
+    if (cus) *cus = ctx->cus;
+    if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+    return TSR_OK;
+}
+
+int tsr_scratch(tsr_ctx *ctx, int slot, size_t bytes, void **out)
+{
+    tsr_devbuf &b = ctx->scratch[slot];
+    if (bytes > b.cap) {
+        if (b.ptr) {
+            TSR_HIP(hipStreamSynchronize(ctx->stream));
+            TSR_HIP(hipFree(b.ptr));
+            b.ptr = nullptr;
+            b.cap = 0;
+        }
+        size_t cap = std::max<size_t>(bytes, 1 << 20);
+        TSR_HIP(hipMalloc(&b.ptr, cap));
+        b.cap = cap;
+    }
+    *out = b.ptr;
+    return TSR_OK;
+}
+
+namespace {
+
+template <typename T>
+int dev_upload(tsr_ctx *ctx, T **dptr, const T *src, size_t count, size_t slack_bytes = 0)
+{
+    *dptr = nullptr;
+    size_t bytes = count * sizeof(T);
+    TSR_HIP(hipMalloc(reinterpret_cast<void **>(dptr), std::max<size_t>(bytes + slack_bytes, 16)));
+    if (slack_bytes) TSR_HIP(hipMemsetAsync(reinterpret_cast<char *>(*dptr) + bytes, 0, slack_bytes, ctx->stream));
+    if (bytes) TSR_HIP(hipMemcpyAsync(*dptr, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return TSR_OK;
+}
+
+void dev_free(void *p)
+{
+    if (p) (void)hipFree(p);
+}
+
+enum { SLOT_RAW = 0, SLOT_IN = 1, SLOT_W = 2, SLOT_OUT = 3, SLOT_AUX = 4, SLOT_AUX2 = 5 };
+
+}  // namespace
+
+// ---- bank ----------------------------------------------------------------------
+static int bank_build_exact(tsr_ctx *ctx, tsr_bank *b)
+{
+    // Wx[g][tau][d4][m][j]  (see tsr_internal.h)
+    const int M = b->M;
+    const int64_t D = b->D;
+    const int Dq = (int)((D + 3) / 4);
+    b->Dq = Dq;
+    b->n_groups = (M + TSR_MG - 1) / TSR_MG;
+    b->gx_off.assign(b->n_groups, 0);
+    b->gx_L.assign(b->n_groups, 0);
+    int64_t total = 0;
+    for (int g = 0; g < b->n_groups; ++g) {
+        int Lg = 0;
+        for (int m = g * TSR_MG; m < std::min(M, (g + 1) * TSR_MG); ++m) Lg = std::max(Lg, b->L[m]);
+        b->gx_off[g] = total;
+        b->gx_L[g] = Lg;
+        total += (int64_t)Lg * Dq * TSR_MG * 4;
+    }
+    std::vector<float> Wx((size_t)total, 0.0f);
+    int64_t woff = 0;
+    for (int m = 0; m < M; ++m) {
+        const int g = m / TSR_MG, mi = m % TSR_MG;
+        float *dst = Wx.data() + b->gx_off[g];
+        const float *src = b->W_cat.data() + woff;
+        for (int tau = 0; tau < b->L[m]; ++tau)
+            for (int64_t d = 0; d < D; ++d)
+                dst[(((int64_t)tau * Dq + d / 4) * TSR_MG + mi) * 4 + (d & 3)] = src[(int64_t)tau * D + d];
+        woff += (int64_t)b->L[m] * D;
+    }
+    dev_free(b->d_Wx);
+    dev_free(b->d_gx_off);
+    dev_free(b->d_gx_L);
+    dev_free(b->d_L);
+    dev_free(b->d_cf);
+    std::vector<float> cf(M);
+    for (int m = 0; m < M; ++m) cf[m] = (float)b->c[m];
+    TSR_TRY(dev_upload(ctx, &b->d_Wx, Wx.data(), Wx.size()));
+    TSR_TRY(dev_upload(ctx, &b->d_gx_off, b->gx_off.data(), b->gx_off.size()));
+    TSR_TRY(dev_upload(ctx, &b->d_gx_L, b->gx_L.data(), b->gx_L.size()));
+    TSR_TRY(dev_upload(ctx, &b->d_L, b->L.data(), b->L.size()));
+    TSR_TRY(dev_upload(ctx, &b->d_cf, cf.data(), cf.size()));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));  // host staging vectors die here
+    return TSR_OK;
+}
+
+TSR_API int tsr_bank_create(tsr_ctx *ctx, const float *W_cat, const int32_t *L, const double *c,
+                            int32_t M, int64_t D, tsr_bank **out)
+{
+    TSR_REQUIRE(ctx && W_cat && L && c && out, "tsr_bank_create: null pointer");
+    *out = nullptr;
+    TSR_REQUIRE(M >= 1 && M <= 65535, "tsr_bank_create: M=%d out of range [1,65535]", M);
+    TSR_REQUIRE(D >= 1 && D <= (1 << 20), "tsr_bank_create: D=%lld out of range", (long long)D);
+    int64_t sumL = 0;
+    int Lmax = 0;
+    for (int m = 0; m < M; ++m) {
+        TSR_REQUIRE(L[m] >= 1 && L[m] <= 65535, "tsr_bank_create: L[%d]=%d out of range [1,65535]", m, L[m]);
+        sumL += L[m];
+        Lmax = std::max(Lmax, L[m]);
+    }
+    const int64_t nW = sumL * D;
+    for (int64_t i = 0; i < nW; ++i)
+        if (!isfinite(W_cat[i])) {
+            tsr_set_error("tsr_bank_create: filter value %lld is not finite", (long long)i);
+            return TSR_ERR_NONFINITE;
+        }
+    for (int m = 0; m < M; ++m)
+        if (!isfinite(c[m])) {
+            tsr_set_error("tsr_bank_create: c[%d] is not finite", m);
+            return TSR_ERR_NONFINITE;
+        }
+    TSR_HIP(hipSetDevice(ctx->device));
+    tsr_bank *b = new (std::nothrow) tsr_bank;
+    TSR_REQUIRE(b, "tsr_bank_create: out of host memory");
+    b->ctx = ctx;
+    b->device = ctx->device;
+    b->M = M;
+    b->D = D;
+    b->Lmax = Lmax;
+    b->sumL = sumL;
+    b->L.assign(L, L + M);
+    b->c.assign(c, c + M);
+    b->W_cat.assign(W_cat, W_cat + nW);
+    int s = bank_build_exact(ctx, b);
+    if (s != TSR_OK) {
+        tsr_bank_destroy(b);
+        return s;
+    }
+    *out = b;
+    return TSR_OK;
+}
+
+TSR_API int tsr_bank_destroy(tsr_bank *b)
+{
+    if (!b) return TSR_OK;
+    // never dereference the ctx here: a child may outlive its context (interpreter
+    // shutdown destroys objects in arbitrary order); hipFree needs only the device.
+    (void)hipSetDevice(b->device);
+    (void)hipDeviceSynchronize();
+    tsr_fast_bank_free(b);
+    dev_free(b->d_Wx);
+    dev_free(b->d_gx_off);
+    dev_free(b->d_gx_L);
+    dev_free(b->d_L);
+    dev_free(b->d_cf);
+    delete b;
+    return TSR_OK;
+}
+
+TSR_API int tsr_bank_info(const tsr_bank *b, int32_t *M, int64_t *D, int32_t *Lmax, int64_t *sumL)
+{
+    TSR_REQUIRE(b, "tsr_bank_info: null bank");
+    if (M) *M = b->M;
+    if (D) *D = b->D;
+    if (Lmax) *Lmax = b->Lmax;
+    if (sumL) *sumL = b->sumL;
+    return TSR_OK;
+}
+
+// ---- corpus ---------------------------------------------------------------------
+static const size_t kFeatSlack = 64 * 1024;  // tiles may read (never use) past the end
+
+TSR_API int tsr_corpus_create(tsr_ctx *ctx, const uint8_t *feats, const int64_t *frame_offsets,
+                              int64_t N, int64_t D, tsr_corpus **out)
+{
+    TSR_REQUIRE(ctx && frame_offsets && out, "tsr_corpus_create: null pointer");
+    *out = nullptr;
+    TSR_REQUIRE(N >= 0 && D >= 1, "tsr_corpus_create: bad N=%lld or D=%lld", (long long)N, (long long)D);
+    TSR_REQUIRE(frame_offsets[0] == 0, "tsr_corpus_create: frame_offsets[0] must be 0");
+    for (int64_t n = 0; n < N; ++n)
+        TSR_REQUIRE(frame_offsets[n + 1] >= frame_offsets[n], "tsr_corpus_create: frame_offsets not monotone at %lld", (long long)n);
+    const int64_t P = frame_offsets[N];
+    TSR_REQUIRE(P < (int64_t)1 << 31, "tsr_corpus_create: %lld frames exceed 2^31-1 per corpus", (long long)P);
+    TSR_REQUIRE(P == 0 || feats, "tsr_corpus_create: null feats");
+    TSR_HIP(hipSetDevice(ctx->device));
+    tsr_corpus *cp = new (std::nothrow) tsr_corpus;
+    TSR_REQUIRE(cp, "tsr_corpus_create: out of host memory");
+    cp->ctx = ctx;
+    cp->device = ctx->device;
+    cp->N = N;
+    cp->D = D;
+    cp->P = P;
+    cp->offsets.assign(frame_offsets, frame_offsets + N + 1);
+    std::vector<int32_t> ub((size_t)P), ue((size_t)P);
+    for (int64_t n = 0; n < N; ++n)
+        for (int64_t p = frame_offsets[n]; p < frame_offsets[n + 1]; ++p) {
+            ub[(size_t)p] = (int32_t)frame_offsets[n];
+            ue[(size_t)p] = (int32_t)frame_offsets[n + 1];
+        }
+    int s = dev_upload(ctx, &cp->d_feats, feats, (size_t)(P * D), kFeatSlack);
+    if (s == TSR_OK) s = dev_upload(ctx, &cp->d_utt_beg, ub.data(), ub.size());
+    if (s == TSR_OK) s = dev_upload(ctx, &cp->d_utt_end, ue.data(), ue.size());
+    if (s == TSR_OK) s = dev_upload<float>(ctx, &cp->d_scores, nullptr, 0, (size_t)P * 4);
+    if (s == TSR_OK) s = dev_upload<int32_t>(ctx, &cp->d_ids, nullptr, 0, (size_t)P * 4);
+    if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        tsr_set_error("tsr_corpus_create: upload failed");
+        s = TSR_ERR_HIP;
+    }
+    if (s != TSR_OK) {
+        tsr_corpus_destroy(cp);
+        return s;
+    }
+    *out = cp;
+    return TSR_OK;
+}
+
+TSR_API int tsr_corpus_destroy(tsr_corpus *cp)
+{
+    if (!cp) return TSR_OK;
+    // never dereference the ctx here: a child may outlive its context (interpreter
+    // shutdown destroys objects in arbitrary order); hipFree needs only the device.
+    (void)hipSetDevice(cp->device);
+    (void)hipDeviceSynchronize();
+    dev_free(cp->d_feats);
+    dev_free(cp->d_utt_beg);
+    dev_free(cp->d_utt_end);
+    dev_free(cp->d_scores);
+    dev_free(cp->d_ids);
+    delete cp;
+    return TSR_OK;
+}
+
+TSR_API int tsr_corpus_frames(const tsr_corpus *cp, int64_t *total_frames)
+{
+    TSR_REQUIRE(cp && total_frames, "tsr_corpus_frames: null pointer");
+    *total_frames = cp->P;
+    return TSR_OK;
+}
+
+static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int flags,
+                             float *d_all)
+{
+    TSR_REQUIRE(ctx && bank && cp, "tsr_corpus_score: null pointer");
+    TSR_REQUIRE(bank->D == cp->D, "tsr_corpus_score: bank D=%lld but corpus D=%lld", (long long)bank->D, (long long)cp->D);
+    TSR_REQUIRE((flags & ~(TSR_FAST)) == 0, "tsr_corpus_score: unknown flags 0x%x", flags);
+    if (cp->P == 0) return TSR_OK;
+    TSR_HIP(hipSetDevice(ctx->device));
+    if (flags & TSR_FAST) {
+        if (!bank->fast) TSR_TRY(tsr_fast_bank_build(ctx, const_cast<tsr_bank *>(bank)));
+        return tsr_launch_fast_bank(ctx, bank, cp->d_feats, cp->P, cp->d_utt_beg, cp->d_utt_end, flags,
+                                    d_all ? nullptr : cp->d_scores, d_all ? nullptr : cp->d_ids, d_all);
+    }
+    void *raw = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_RAW, (size_t)bank->M * cp->P * sizeof(float), &raw));
+    TSR_TRY(tsr_launch_exact_bank(ctx, bank, cp->d_feats, cp->P, (float *)raw));
+    return tsr_launch_bank_epilogue(ctx, bank, (const float *)raw, cp->P, cp->d_utt_end, flags,
+                                    d_all ? nullptr : cp->d_scores, d_all ? nullptr : cp->d_ids, d_all);
+}
+
+TSR_API int tsr_corpus_score(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int flags)
+{
+    return corpus_score_impl(ctx, bank, cp, flags, nullptr);
+}
+
+TSR_API int tsr_corpus_download(tsr_ctx *ctx, const tsr_corpus *cp, float *scores, int32_t *ids)
+{
+    TSR_REQUIRE(ctx && cp, "tsr_corpus_download: null pointer");
+    TSR_HIP(hipSetDevice(ctx->device));
+    if (scores && cp->P) TSR_HIP(hipMemcpyAsync(scores, cp->d_scores, (size_t)cp->P * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (ids && cp->P) TSR_HIP(hipMemcpyAsync(ids, cp->d_ids, (size_t)cp->P * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    return TSR_OK;
+}
+
+TSR_API int tsr_score_bank_u8(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *feats,
+                              const int64_t *frame_offsets, int64_t N, int flags, float *scores,
+                              int32_t *ids)
+{
+    TSR_REQUIRE(ctx && bank, "tsr_score_bank_u8: null pointer");
+    tsr_corpus *cp = nullptr;
+    TSR_TRY(tsr_corpus_create(ctx, feats, frame_offsets, N, bank->D, &cp));
+    int s = tsr_corpus_score(ctx, bank, cp, flags);
+    if (s == TSR_OK) s = tsr_corpus_download(ctx, cp, scores, ids);
+    tsr_corpus_destroy(cp);
+    return s;
+}
+
+TSR_API int tsr_score_bank_all_u8(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *feats,
+                                  const int64_t *frame_offsets, int64_t N, int flags,
+                                  float *per_template)
+{
+    TSR_REQUIRE(ctx && bank && per_template, "tsr_score_bank_all_u8: null pointer");
+    tsr_corpus *cp = nullptr;
+    TSR_TRY(tsr_corpus_create(ctx, feats, frame_offsets, N, bank->D, &cp));
+    int s = TSR_OK;
+    void *d_all = nullptr;
+    const size_t bytes = (size_t)bank->M * cp->P * sizeof(float);
+    if (cp->P) {
+        s = tsr_scratch(ctx, SLOT_OUT, bytes, &d_all);
+        if (s == TSR_OK) s = corpus_score_impl(ctx, bank, cp, flags, (float *)d_all);
+        if (s == TSR_OK && hipMemcpyAsync(per_template, d_all, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
+        if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
+        if (s == TSR_ERR_HIP) tsr_set_error("tsr_score_bank_all_u8: device copy failed");
+    }
+    tsr_corpus_destroy(cp);
+    return s;
+}
+
+// ---- single-utterance drop-ins ----------------------------------------------------
+TSR_API int tsr_detect_u8(tsr_ctx *ctx, const uint8_t *F, int64_t T, int64_t D, const float *LF,
+                          int64_t L, float *out)
+{
+    TSR_REQUIRE(ctx && F && LF && out, "tsr_detect_u8: null pointer");
+    TSR_REQUIRE(L >= 1 && T >= L, "tsr_detect_u8: need T >= L >= 1 (T=%lld, L=%lld); the reference reads out of bounds here", (long long)T, (long long)L);
+    const int32_t L32 = (int32_t)L;
+    const double c0 = 0.0;
+    const int64_t offs[2] = {0, T};
+    tsr_bank *bank = nullptr;
+    TSR_TRY(tsr_bank_create(ctx, LF, &L32, &c0, 1, D, &bank));
+    int s = tsr_score_bank_all_u8(ctx, bank, F, offs, 1, TSR_EXACT, out);
+    tsr_bank_destroy(bank);
+    return s;
+}
+
+static int detect_f32_common(tsr_ctx *ctx, const float *F, int64_t T, int64_t D, const float *LF,
+                             int64_t M, int64_t L, const float *cs, std::vector<float> &host_all)
+{
+    TSR_REQUIRE(L >= 1 && T >= L && M >= 1 && D >= 1, "detect_f32: need T >= L >= 1 (T=%lld, L=%lld)", (long long)T, (long long)L);
+    TSR_REQUIRE(T <= 65535 * 256 && L * D < ((int64_t)1 << 31), "detect_f32: sizes out of range");
+    TSR_HIP(hipSetDevice(ctx->device));
+    void *dF, *dW, *dO, *dC = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_IN, (size_t)(T * D) * 4, &dF));
+    TSR_TRY(tsr_scratch(ctx, SLOT_W, (size_t)(M * L * D) * 4, &dW));
+    TSR_TRY(tsr_scratch(ctx, SLOT_OUT, (size_t)(M * T) * 4, &dO));
+    TSR_HIP(hipMemcpyAsync(dF, F, (size_t)(T * D) * 4, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(dW, LF, (size_t)(M * L * D) * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (cs) {
+        TSR_TRY(tsr_scratch(ctx, SLOT_AUX, (size_t)M * 4, &dC));
+        TSR_HIP(hipMemcpyAsync(dC, cs, (size_t)M * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    TSR_TRY(tsr_launch_detect_f32(ctx, (const float *)dF, T, D, (const float *)dW, M, L, (const float *)dC, (float *)dO, nullptr));
+    host_all.resize((size_t)(M * T));
+    TSR_HIP(hipMemcpyAsync(host_all.data(), dO, (size_t)(M * T) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    return TSR_OK;
+}
+
+TSR_API int tsr_detect_f32(tsr_ctx *ctx, const float *F, int64_t T, int64_t D, const float *LF,
+                           int64_t L, float *out)
+{
+    TSR_REQUIRE(ctx && F && LF && out, "tsr_detect_f32: null pointer");
+    std::vector<float> all;
+    TSR_TRY(detect_f32_common(ctx, F, T, D, LF, 1, L, nullptr, all));
+    memcpy(out, all.data(), (size_t)T * 4);
+    return TSR_OK;
+}
+
+TSR_API int tsr_detect_f32_max(tsr_ctx *ctx, const float *F, int64_t T, int64_t D, const float *LF,
+                               int64_t M, int64_t L, const float *cs, float *out, uint16_t *ids)
+{
+    TSR_REQUIRE(ctx && F && LF && cs && out && ids, "tsr_detect_f32_max: null pointer");
+    TSR_REQUIRE(M <= 65535, "tsr_detect_f32_max: M=%lld exceeds the uint16 id range", (long long)M);
+    std::vector<float> all;
+    TSR_TRY(detect_f32_common(ctx, F, T, D, LF, M, L, cs, all));
+    // first maximum, strict '>' (compute_likelihood_linear_filter.pyx:270-277); the
+    // tail t > T-L stays (0, 0) like the reference's zero-initialised outputs.
+    for (int64_t t = 0; t < T; ++t) {
+        if (t + L > T) {
+            out[t] = 0.0f;
+            ids[t] = 0;
+            continue;
+        }
+        float best = all[(size_t)t];
+        uint16_t bi = 0;
+        for (int64_t m = 1; m < M; ++m) {
+            const float v = all[(size_t)(m * T + t)];
+            if (v > best) {
+                best = v;
+                bi = (uint16_t)m;
+            }
+        }
+        out[t] = best;
+        ids[t] = bi;
+    }
+    return TSR_OK;
+}
+
+TSR_API int tsr_max_detect_examples_u8(tsr_ctx *ctx, const uint8_t *F, int64_t N, int64_t T,
+                                       int64_t D, const double *LF, int64_t L,
+                                       const int64_t *lengths, double *out)
+{
+    TSR_REQUIRE(ctx && F && LF && lengths && out, "tsr_max_detect_examples_u8: null pointer");
+    TSR_REQUIRE(N >= 0 && T >= 1 && D >= 1 && L >= 1, "tsr_max_detect_examples_u8: bad sizes");
+    TSR_REQUIRE(N <= 65535 && L * D < ((int64_t)1 << 31), "tsr_max_detect_examples_u8: sizes out of range");
+    for (int64_t n = 0; n < N; ++n)
+        TSR_REQUIRE(lengths[n] >= 0 && lengths[n] <= T, "tsr_max_detect_examples_u8: lengths[%lld]=%lld outside [0,T]", (long long)n, (long long)lengths[n]);
+    if (N == 0) return TSR_OK;
+    TSR_HIP(hipSetDevice(ctx->device));
+    void *dF, *dW, *dT;
+    TSR_TRY(tsr_scratch(ctx, SLOT_IN, (size_t)(N * T * D), &dF));
+    TSR_TRY(tsr_scratch(ctx, SLOT_W, (size_t)(L * D) * 8, &dW));
+    TSR_TRY(tsr_scratch(ctx, SLOT_OUT, (size_t)(N * T) * 8, &dT));
+    TSR_HIP(hipMemcpyAsync(dF, F, (size_t)(N * T * D), hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(dW, LF, (size_t)(L * D) * 8, hipMemcpyHostToDevice, ctx->stream));
+    TSR_TRY(tsr_launch_max_detect_examples(ctx, (const uint8_t *)dF, N, T, D, (const double *)dW, L, nullptr, (double *)dT, nullptr));
+    std::vector<double> tmp((size_t)(N * T));
+    TSR_HIP(hipMemcpyAsync(tmp.data(), dT, tmp.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    for (int64_t n = 0; n < N; ++n) {  // :69-70: first t initialises, then strict '>'
+        double best = 0.0;
+        for (int64_t t = 0; t < lengths[n]; ++t) {
+            const double v = tmp[(size_t)(n * T + t)];
+            if (t == 0 || v > best) best = v;
+        }
+        out[n] = best;
+    }
+    return TSR_OK;
+}
+
+// ---- front-end --------------------------------------------------------------------
+TSR_API int tsr_parts_create(tsr_ctx *ctx, const double *lp, const double *lip, int64_t K,
+                             int64_t P0, int64_t P1, int64_t E, tsr_parts **out)
+{
+    TSR_REQUIRE(ctx && lp && lip && out, "tsr_parts_create: null pointer");
+    *out = nullptr;
+    TSR_REQUIRE(K >= 1 && P0 >= 1 && P1 >= 1 && E >= 1 && K <= 65535 && P0 * P1 * E <= (1 << 20), "tsr_parts_create: bad geometry");
+    TSR_HIP(hipSetDevice(ctx->device));
+    const int64_t Q = P0 * P1 * E;
+    std::vector<double> tab((size_t)(Q * K * 2));
+    for (int64_t k = 0; k < K; ++k)
+        for (int64_t q = 0; q < Q; ++q) {
+            tab[(size_t)((q * K + k) * 2 + 0)] = lip[k * Q + q];
+            tab[(size_t)((q * K + k) * 2 + 1)] = lp[k * Q + q];
+        }
+    tsr_parts *p = new (std::nothrow) tsr_parts;
+    TSR_REQUIRE(p, "tsr_parts_create: out of host memory");
+    p->ctx = ctx;
+    p->device = ctx->device;
+    p->K = K;
+    p->P0 = P0;
+    p->P1 = P1;
+    p->E = E;
+    int s = dev_upload(ctx, &p->d_tab, tab.data(), tab.size());
+    if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
+    if (s != TSR_OK) {
+        tsr_parts_destroy(p);
+        return s;
+    }
+    *out = p;
+    return TSR_OK;
+}
+
+TSR_API int tsr_parts_destroy(tsr_parts *p)
+{
+    if (!p) return TSR_OK;
+    // never dereference the ctx here: a child may outlive its context (interpreter
+    // shutdown destroys objects in arbitrary order); hipFree needs only the device.
+    (void)hipSetDevice(p->device);
+    (void)hipDeviceSynchronize();
+    dev_free(p->d_tab);
+    delete p;
+    return TSR_OK;
+}
+
+TSR_API int tsr_code_parts(tsr_ctx *ctx, const uint8_t *X, int64_t X0, int64_t X1, int64_t E,
+                           const double *lp, const double *lip, int64_t K, int64_t P0, int64_t P1,
+                           int threshold, int fast, double *out)
+{
+    TSR_REQUIRE(ctx && X && lp && lip && out, "tsr_code_parts: null pointer");
+    TSR_REQUIRE(X0 >= P0 && X1 >= P1 && P0 >= 1 && P1 >= 1, "tsr_code_parts: patch %lldx%lld larger than map %lldx%lld", (long long)P0, (long long)P1, (long long)X0, (long long)X1);
+    TSR_REQUIRE(X0 * X1 * E < ((int64_t)1 << 31), "tsr_code_parts: map too large");
+    tsr_parts *parts = nullptr;
+    TSR_TRY(tsr_parts_create(ctx, lp, lip, K, P0, P1, E, &parts));
+    const int64_t n_loc = (X0 - P0 + 1) * (X1 - P1 + 1);
+    void *dX, *dO;
+    int s = tsr_scratch(ctx, SLOT_IN, (size_t)(X0 * X1 * E), &dX);
+    if (s == TSR_OK) s = tsr_scratch(ctx, SLOT_OUT, (size_t)(n_loc * (K + 1)) * 8, &dO);
+    if (s == TSR_OK && hipMemcpyAsync(dX, X, (size_t)(X0 * X1 * E), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
+    if (s == TSR_OK) s = tsr_launch_code_parts(ctx, parts, (const uint8_t *)dX, X0, X1, threshold, fast, (double *)dO, nullptr);
+    if (s == TSR_OK && hipMemcpyAsync(out, dO, (size_t)(n_loc * (K + 1)) * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
+    if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
+    if (s == TSR_ERR_HIP) tsr_set_error("tsr_code_parts: device copy/launch failed");
+    tsr_parts_destroy(parts);
+    return s;
+}
+
+static int upload_part_ids(tsr_ctx *ctx, const int64_t *X, int64_t n, int64_t K, void **dA)
+{
+    std::vector<int32_t> a((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        TSR_REQUIRE(X[i] <= K, "spread_patches: part id %lld exceeds num_parts=%lld (the reference writes out of bounds here)", (long long)X[i], (long long)K);
+        a[(size_t)i] = X[i] > 0 ? (int32_t)X[i] : 0;
+    }
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX, (size_t)n * 4, dA));
+    TSR_HIP(hipMemcpyAsync(*dA, a.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    return TSR_OK;
+}
+
+TSR_API int tsr_spread_patches(tsr_ctx *ctx, const int64_t *X, int64_t X0, int64_t X1, int r0,
+                               int r1, int64_t K, uint8_t *out)
+{
+    TSR_REQUIRE(ctx && X && out, "tsr_spread_patches: null pointer");
+    TSR_REQUIRE(X0 >= 0 && X1 >= 0 && K >= 0 && X0 <= 65535 && X1 <= 65535, "tsr_spread_patches: bad sizes (the reference stores the map shape in uint16)");
+    TSR_REQUIRE(r0 >= 0 && r1 >= 0, "tsr_spread_patches: negative spread radius");
+    const int64_t n = X0 * X1;
+    if (n == 0 || K == 0) return TSR_OK;
+    TSR_HIP(hipSetDevice(ctx->device));
+    void *dA, *dO;
+    TSR_TRY(upload_part_ids(ctx, X, n, K, &dA));
+    TSR_TRY(tsr_scratch(ctx, SLOT_OUT, (size_t)(n * K), &dO));
+    TSR_TRY(tsr_launch_spread(ctx, (const int32_t *)dA, X0, X1, r0, r1, K, 1, 1, nullptr, (uint8_t *)dO));
+    TSR_HIP(hipMemcpyAsync(out, dO, (size_t)(n * K), hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    return TSR_OK;
+}
+
+TSR_API int tsr_spread_graph_patches(tsr_ctx *ctx, uint8_t *X, int64_t X0, int64_t X1, int64_t K,
+                                     const uint8_t *graph)
+{
+    TSR_REQUIRE(ctx && X && graph, "tsr_spread_graph_patches: null pointer");
+    const int64_t n = X0 * X1;
+    if (n <= 0 || K <= 0) return TSR_OK;
+    TSR_HIP(hipSetDevice(ctx->device));
+    void *dX, *dG;
+    TSR_TRY(tsr_scratch(ctx, SLOT_OUT, (size_t)(n * K), &dX));
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX2, (size_t)(K * K), &dG));
+    TSR_HIP(hipMemcpyAsync(dX, X, (size_t)(n * K), hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(dG, graph, (size_t)(K * K), hipMemcpyHostToDevice, ctx->stream));
+    TSR_TRY(tsr_launch_spread_graph(ctx, (uint8_t *)dX, n, K, (const uint8_t *)dG));
+    TSR_HIP(hipMemcpyAsync(X, dX, (size_t)(n * K), hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    return TSR_OK;
+}
+
+TSR_API int tsr_part_features(tsr_ctx *ctx, const tsr_parts *parts, const uint8_t *X, int64_t X0,
+                              int64_t X1, int threshold, int fast, int r0, int r1,
+                              const uint8_t *graph, int g0, int g1, uint8_t *out,
+                              int64_t *argmax_out)
+{
+    TSR_REQUIRE(ctx && parts && X && out, "tsr_part_features: null pointer");
+    TSR_REQUIRE(X0 >= parts->P0 && X1 >= parts->P1, "tsr_part_features: map smaller than the patch");
+    TSR_REQUIRE(r0 >= 0 && r1 >= 0 && g0 >= 1 && g1 >= 1, "tsr_part_features: bad radius/grid");
+    TSR_REQUIRE(X0 * X1 * parts->E < ((int64_t)1 << 31), "tsr_part_features: map too large");
+    TSR_HIP(hipSetDevice(ctx->device));
+    const int64_t N0 = X0 - parts->P0 + 1, N1 = X1 - parts->P1 + 1, K = parts->K;
+    const int64_t O0 = (N0 + g0 - 1) / g0, O1 = (N1 + g1 - 1) / g1;
+    void *dX, *dA, *dO, *dG = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_IN, (size_t)(X0 * X1 * parts->E), &dX));
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX, (size_t)(N0 * N1) * 4, &dA));
+    TSR_TRY(tsr_scratch(ctx, SLOT_OUT, (size_t)(O0 * O1 * K), &dO));
+    TSR_HIP(hipMemcpyAsync(dX, X, (size_t)(X0 * X1 * parts->E), hipMemcpyHostToDevice, ctx->stream));
+    if (graph) {
+        TSR_TRY(tsr_scratch(ctx, SLOT_AUX2, (size_t)(K * K), &dG));
+        TSR_HIP(hipMemcpyAsync(dG, graph, (size_t)(K * K), hipMemcpyHostToDevice, ctx->stream));
+    }
+    TSR_TRY(tsr_launch_code_parts(ctx, parts, (const uint8_t *)dX, X0, X1, threshold, fast, nullptr, (int32_t *)dA));
+    TSR_TRY(tsr_launch_spread(ctx, (const int32_t *)dA, N0, N1, r0, r1, K, g0, g1, (const uint8_t *)dG, (uint8_t *)dO));
+    TSR_HIP(hipMemcpyAsync(out, dO, (size_t)(O0 * O1 * K), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<int32_t> am;
+    if (argmax_out) {
+        am.resize((size_t)(N0 * N1));
+        TSR_HIP(hipMemcpyAsync(am.data(), dA, am.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    if (argmax_out)
+        for (size_t i = 0; i < am.size(); ++i) argmax_out[i] = am[i];
+    return TSR_OK;
+}
+
+// ---- multi-GPU: RCCL bank broadcast (librccl resolved at run time) -------------------
+namespace {
+struct uid128 {  // ncclUniqueId: 128 opaque bytes, passed by value
+    char b[128];
+};
+struct rccl_api {
+    void *h = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, uid128, int) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+rccl_api g_rccl;
+}  // namespace
+
+static int rccl_load()
+{
+    if (g_rccl.h) return TSR_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) {
+        tsr_set_error("RCCL: cannot dlopen librccl (%s)", dlerror());
+        return TSR_ERR_RCCL;
+    }
+    g_rccl.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void **, int, uid128, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.Broadcast = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclBroadcast");
+    g_rccl.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.Broadcast || !g_rccl.CommDestroy) {
+        tsr_set_error("RCCL: librccl lacks a required symbol");
+        dlclose(h);
+        return TSR_ERR_RCCL;
+    }
+    g_rccl.h = h;
+    return TSR_OK;
+}
+
+#define TSR_NCCL(call)                                                                      \
+    do {                                                                                    \
+        int _r = (call);                                                                    \
+        if (_r != 0) {                                                                      \
+            tsr_set_error("%s failed: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "?"); \
+            return TSR_ERR_RCCL;                                                            \
+        }                                                                                   \
+    } while (0)
+
+TSR_API int tsr_dist_unique_id(char id[128])
+{
+    TSR_REQUIRE(id, "tsr_dist_unique_id: null pointer");
+    TSR_TRY(rccl_load());
+    TSR_NCCL(g_rccl.GetUniqueId(id));
+    return TSR_OK;
+}
+
+TSR_API int tsr_dist_init(tsr_ctx *ctx, const char id[128], int nranks, int rank)
+{
+    TSR_REQUIRE(ctx && id, "tsr_dist_init: null pointer");
+    TSR_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "tsr_dist_init: bad rank %d of %d", rank, nranks);
+    TSR_REQUIRE(!ctx->comm, "tsr_dist_init: communicator already initialised");
+    TSR_TRY(rccl_load());
+    TSR_HIP(hipSetDevice(ctx->device));
+    uid128 u;
+    memcpy(u.b, id, 128);
+    TSR_NCCL(g_rccl.CommInitRank(&ctx->comm, nranks, u, rank));
+    ctx->nranks = nranks;
+    ctx->rank = rank;
+    return TSR_OK;
+}
+
+TSR_API int tsr_dist_finalize(tsr_ctx *ctx)
+{
+    TSR_REQUIRE(ctx, "tsr_dist_finalize: null ctx");
+    if (ctx->comm && g_rccl.CommDestroy) {
+        (void)hipStreamSynchronize(ctx->stream);
+        g_rccl.CommDestroy(ctx->comm);
+    }
+    ctx->comm = nullptr;
+    ctx->nranks = 1;
+    ctx->rank = 0;
+    return TSR_OK;
+}
+
+TSR_API int tsr_bank_broadcast(tsr_ctx *ctx, tsr_bank *bank, int root)
+{
+    TSR_REQUIRE(ctx && bank, "tsr_bank_broadcast: null pointer");
+    TSR_REQUIRE(ctx->comm, "tsr_bank_broadcast: call tsr_dist_init first");
+    TSR_REQUIRE(root >= 0 && root < ctx->nranks, "tsr_bank_broadcast: bad root %d", root);
+    TSR_HIP(hipSetDevice(ctx->device));
+    // Canonical form travels: [L i32 x M | pad][c f64 x M][W_cat f32 x sumL*D]; every rank
+    // then rebuilds its kernel-side layouts from it.
+    const size_t nW = bank->W_cat.size();
+    const size_t offC = ((size_t)bank->M * 4 + 7) & ~(size_t)7;
+    const size_t offW = offC + (size_t)bank->M * 8;
+    const size_t bytes = offW + nW * 4;
+    std::vector<char> host(bytes, 0);
+    memcpy(host.data(), bank->L.data(), (size_t)bank->M * 4);
+    memcpy(host.data() + offC, bank->c.data(), (size_t)bank->M * 8);
+    memcpy(host.data() + offW, bank->W_cat.data(), nW * 4);
+    void *d = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_W, bytes, &d));
+    TSR_HIP(hipMemcpyAsync(d, host.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+    TSR_NCCL(g_rccl.Broadcast(d, d, bytes, /*ncclChar*/ 0, root, ctx->comm, ctx->stream));
+    std::vector<char> back(bytes);
+    TSR_HIP(hipMemcpyAsync(back.data(), d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    if (memcmp(back.data(), bank->L.data(), (size_t)bank->M * 4) != 0) {
+        tsr_set_error("tsr_bank_broadcast: rank %d's bank geometry (template lengths) differs from root's", ctx->rank);
+        return TSR_ERR_INVALID;
+    }
+    if (ctx->rank != root) {
+        memcpy(bank->c.data(), back.data() + offC, (size_t)bank->M * 8);
+        memcpy(bank->W_cat.data(), back.data() + offW, nW * 4);
+        TSR_TRY(bank_build_exact(ctx, bank));
+        tsr_fast_bank_free(bank);  // rebuilt lazily from the new weights
+    }
+    return TSR_OK;
+}

@@ -1,0 +1,138 @@
+// tsr_internal.h -- shared internals of libtsr_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/tsr.h"
+
+#define TSR_API extern "C" __attribute__((visibility("default")))
+
+void tsr_set_error(const char *fmt, ...);
+
+#define TSR_HIP(call)                                                                     \
+    do {                                                                                  \
+        hipError_t _e = (call);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            tsr_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, \
+                          __LINE__);                                                      \
+            return (_e == hipErrorNoDevice || _e == hipErrorInvalidDevice) ? TSR_ERR_NO_DEVICE \
+                                                                          : TSR_ERR_HIP;  \
+        }                                                                                 \
+    } while (0)
+
+#define TSR_REQUIRE(cond, ...)        \
+    do {                              \
+        if (!(cond)) {                \
+            tsr_set_error(__VA_ARGS__); \
+            return TSR_ERR_INVALID;   \
+        }                             \
+    } while (0)
+
+#define TSR_TRY(expr)                 \
+    do {                              \
+        int _s = (expr);              \
+        if (_s != TSR_OK) return _s;  \
+    } while (0)
+
+// A growable device scratch buffer owned by the ctx (never shrinks).
+struct tsr_devbuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+};
+
+struct tsr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int cus = 0;
+    int64_t hbm_bytes = 0;
+    char name[128] = {0};
+    tsr_devbuf scratch[8];  // per-purpose scratch slots (see tsr_scratch)
+    void *comm = nullptr;   // ncclComm_t when tsr_dist_init has run
+    int nranks = 1, rank = 0;
+};
+
+int tsr_scratch(tsr_ctx *ctx, int slot, size_t bytes, void **out);
+
+// ---- bank ---------------------------------------------------------------------
+// Exact path: templates in groups of TSR_MG; group g holds, for every (tau, d4),
+// TSR_MG x 4 floats  Wx[g][tau][d4][m][j] = W_{g*MG+m}[tau][4*d4+j]  (zero padded
+// in tau beyond L_m, in d beyond D and for m beyond M), so that one wave-uniform
+// 16-float line feeds 4 templates x 4 consecutive features.
+#define TSR_MG 4
+
+// Fast (MFMA) path: see detect_mfma.hip for the limb layout.
+struct tsr_bank {
+    tsr_ctx *ctx = nullptr;
+    int device = 0;
+    int32_t M = 0;
+    int64_t D = 0;
+    int32_t Lmax = 0;
+    int64_t sumL = 0;
+    std::vector<int32_t> L;   // host copies
+    std::vector<double> c;
+    std::vector<float> W_cat; // host copy (needed to rebuild device forms after a broadcast)
+    // device, exact path
+    int32_t n_groups = 0;
+    int32_t Dq = 0;                  // ceil(D/4)
+    float *d_Wx = nullptr;           // all groups back to back
+    std::vector<int64_t> gx_off;     // float offset of group g in d_Wx
+    std::vector<int32_t> gx_L;       // max L in group g
+    int64_t *d_gx_off = nullptr;     // device copies of the two tables above
+    int32_t *d_gx_L = nullptr;
+    int32_t *d_L = nullptr;          // [M]
+    float *d_cf = nullptr;           // [M]  f32(c_m)
+    // device, fast path (built lazily by detect_mfma.hip)
+    void *fast = nullptr;
+};
+
+struct tsr_corpus {
+    tsr_ctx *ctx = nullptr;
+    int device = 0;
+    int64_t N = 0, D = 0, P = 0;     // P = total frames
+    uint8_t *d_feats = nullptr;      // [P, D] (+ slack so that tiles may over-read)
+    int32_t *d_utt_end = nullptr;    // [P] end frame (exclusive) of the utterance holding p
+    int32_t *d_utt_beg = nullptr;    // [P] first frame of the utterance holding p
+    float *d_scores = nullptr;       // [P]
+    int32_t *d_ids = nullptr;        // [P]
+    std::vector<int64_t> offsets;    // host [N+1]
+};
+
+struct tsr_parts {
+    tsr_ctx *ctx = nullptr;
+    int device = 0;
+    int64_t K = 0, P0 = 0, P1 = 0, E = 0;
+    double *d_tab = nullptr;  // [q][k][2] = {log_invparts, log_parts}, q = (i*P1+j)*E+z
+};
+
+// ---- kernels' host entry points (device pointers, enqueue on ctx->stream) -----
+// detect_exact.hip
+int tsr_launch_exact_bank(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *d_feats, int64_t P,
+                          float *d_raw /*[M][P]*/);
+int tsr_launch_bank_epilogue(tsr_ctx *ctx, const tsr_bank *bank, const float *d_raw, int64_t P,
+                             const int32_t *d_utt_end, int flags, float *d_scores, int32_t *d_ids,
+                             float *d_all /*[M][P] or null*/);
+int tsr_launch_detect_f32(tsr_ctx *ctx, const float *d_F, int64_t T, int64_t D, const float *d_LF,
+                          int64_t M, int64_t L, const float *d_cs, float *d_out, uint16_t *d_ids);
+int tsr_launch_max_detect_examples(tsr_ctx *ctx, const uint8_t *d_F, int64_t N, int64_t T,
+                                   int64_t D, const double *d_LF, int64_t L,
+                                   const int64_t *d_lengths, double *d_tmp, double *d_out);
+// detect_mfma.hip
+int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank);
+void tsr_fast_bank_free(tsr_bank *bank);
+int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *d_feats, int64_t P,
+                         const int32_t *d_utt_beg, const int32_t *d_utt_end, int flags,
+                         float *d_scores, int32_t *d_ids, float *d_all);
+// parts.hip
+int tsr_launch_code_parts(tsr_ctx *ctx, const tsr_parts *parts, const uint8_t *d_X, int64_t X0,
+                          int64_t X1, int threshold, int fast, double *d_out /*or null*/,
+                          int32_t *d_argmax /*or null*/);
+int tsr_launch_spread(tsr_ctx *ctx, const int32_t *d_A, int64_t X0, int64_t X1, int r0, int r1,
+                      int64_t K, int g0, int g1, const uint8_t *d_graph, uint8_t *d_out);
+int tsr_launch_spread_graph(tsr_ctx *ctx, uint8_t *d_X, int64_t n_loc, int64_t K,
+                            const uint8_t *d_graph);

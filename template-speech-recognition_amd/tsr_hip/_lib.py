@@ -1,0 +1,97 @@
+"""ctypes binding of libtsr_hip.so (include/tsr.h).  No CPU fallback: if the
+library or a gfx950 device is missing, calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "lib", "libtsr_hip.so")
+
+TSR_OK, TSR_ERR_INVALID, TSR_ERR_HIP, TSR_ERR_NO_DEVICE, TSR_ERR_UNSUPPORTED, TSR_ERR_NONFINITE, \
+    TSR_ERR_RCCL = range(7)
+TSR_EXACT, TSR_FAST = 0, 1
+
+_i32, _i64, _int, _p, _f = C.c_int32, C.c_int64, C.c_int, C.c_void_p, C.c_float
+_pp = C.POINTER(C.c_void_p)
+
+# name -> argtypes, exactly the declarations of include/tsr.h (restype is int unless noted)
+SIGNATURES = {
+    "tsr_version": [],
+    "tsr_device_count": [C.POINTER(_int)],
+    "tsr_ctx_create": [_int, _pp],
+    "tsr_ctx_destroy": [_p],
+    "tsr_ctx_sync": [_p],
+    "tsr_timer_start": [_p],
+    "tsr_timer_stop": [_p, C.POINTER(_f)],
+    "tsr_device_info": [_p, C.c_char_p, _int, C.POINTER(_int), C.POINTER(_i64)],
+    "tsr_detect_u8": [_p, _p, _i64, _i64, _p, _i64, _p],
+    "tsr_detect_f32": [_p, _p, _i64, _i64, _p, _i64, _p],
+    "tsr_detect_f32_max": [_p, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _p],
+    "tsr_max_detect_examples_u8": [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _p],
+    "tsr_bank_create": [_p, _p, _p, _p, _i32, _i64, _pp],
+    "tsr_bank_destroy": [_p],
+    "tsr_bank_info": [_p, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i64)],
+    "tsr_score_bank_u8": [_p, _p, _p, _p, _i64, _int, _p, _p],
+    "tsr_score_bank_all_u8": [_p, _p, _p, _p, _i64, _int, _p],
+    "tsr_corpus_create": [_p, _p, _p, _i64, _i64, _pp],
+    "tsr_corpus_destroy": [_p],
+    "tsr_corpus_score": [_p, _p, _p, _int],
+    "tsr_corpus_download": [_p, _p, _p, _p],
+    "tsr_corpus_frames": [_p, C.POINTER(_i64)],
+    "tsr_code_parts": [_p, _p, _i64, _i64, _i64, _p, _p, _i64, _i64, _i64, _int, _int, _p],
+    "tsr_spread_patches": [_p, _p, _i64, _i64, _int, _int, _i64, _p],
+    "tsr_spread_graph_patches": [_p, _p, _i64, _i64, _i64, _p],
+    "tsr_parts_create": [_p, _p, _p, _i64, _i64, _i64, _i64, _pp],
+    "tsr_parts_destroy": [_p],
+    "tsr_part_features": [_p, _p, _p, _i64, _i64, _int, _int, _int, _int, _p, _int, _int, _p, _p],
+    "tsr_dist_unique_id": [C.c_char_p],
+    "tsr_dist_init": [_p, C.c_char_p, _int, _int],
+    "tsr_dist_finalize": [_p],
+    "tsr_bank_broadcast": [_p, _p, _int],
+}
+_STR_FUNCS = {"tsr_strerror": [_int], "tsr_last_error": []}
+
+_lib = None
+
+
+class TsrError(RuntimeError):
+    def __init__(self, status, message):
+        RuntimeError.__init__(self, "libtsr_hip: %s" % message)
+        self.status = status
+
+
+def lib():
+    """Load libtsr_hip.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libtsr_hip.so is missing at %s: build it with "
+                               "`python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback)" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = _int
+        for name, args in _STR_FUNCS.items():
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = C.c_char_p
+        _lib = l
+    return _lib
+
+
+def check(status):
+    """Map a C status to the Python exception the reference's callers expect."""
+    if status == TSR_OK:
+        return
+    l = lib()
+    msg = l.tsr_last_error().decode() or l.tsr_strerror(status).decode()
+    if status == TSR_ERR_INVALID:
+        raise ValueError(msg)
+    raise TsrError(status, "%s [%s]" % (msg, l.tsr_strerror(status).decode()))
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(_p)

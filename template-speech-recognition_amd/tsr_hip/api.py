@@ -1,0 +1,241 @@
+"""Batched, device-resident face of libtsr_hip.so: Context, Bank, Corpus, Parts.
+
+This is the host-side counterpart of the reference's per-utterance glue
+(get_train_data.py:927-1012 `_compute_detection_E`, :2576-2631
+`get_part_features`, :138-201 `get_waliji_feature_map`), re-shaped so that a
+whole corpus is scored by one call with inputs and outputs resident in HBM.
+NumPy + ctypes only.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import TSR_EXACT, TSR_FAST, check, lib, ptr
+
+_default_ctx = None
+
+
+class Context:
+    """One GPU, one HIP stream, scratch buffers (tsr_ctx).  Not thread-safe."""
+
+    def __init__(self, device=None):
+        if device is None:
+            device = int(os.environ.get("TSR_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        h = C.c_void_p()
+        check(lib().tsr_ctx_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tsr_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(lib().tsr_ctx_sync(self._h))
+
+    def timer_start(self):
+        check(lib().tsr_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        check(lib().tsr_timer_stop(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def info(self):
+        name = C.create_string_buffer(128)
+        cus, hbm = C.c_int(), C.c_int64()
+        check(lib().tsr_device_info(self._h, name, 128, C.byref(cus), C.byref(hbm)))
+        return dict(name=name.value.decode(), cus=int(cus.value), hbm_bytes=int(hbm.value))
+
+    # ---- multi-GPU (one process per GPU; see tsr_hip.dist) -------------------------
+    def dist_init(self, unique_id, nranks, rank):
+        check(lib().tsr_dist_init(self._h, unique_id, int(nranks), int(rank)))
+
+    def dist_finalize(self):
+        check(lib().tsr_dist_finalize(self._h))
+
+
+def default_ctx():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx
+
+
+def device_count():
+    n = C.c_int()
+    check(lib().tsr_device_count(C.byref(n)))
+    return int(n.value)
+
+
+def unique_id():
+    buf = C.create_string_buffer(128)
+    check(lib().tsr_dist_unique_id(buf))
+    return buf.raw
+
+
+def pack_filters(linear_filters_cs):
+    """((W_m [L_m, ...], c_m), ...) -> (W_cat f32, L i32 [M], c f64 [M], D)."""
+    Ws = [np.ascontiguousarray(w, dtype=np.float32) for w, _ in linear_filters_cs]
+    if not Ws:
+        raise ValueError("empty template bank")
+    D = int(np.prod(Ws[0].shape[1:], dtype=np.int64))
+    for w in Ws:
+        if w.ndim < 2 or int(np.prod(w.shape[1:], dtype=np.int64)) != D:
+            raise ValueError("all templates must share the feature shape %r" % (Ws[0].shape[1:],))
+    L = np.array([w.shape[0] for w in Ws], np.int32)
+    W_cat = np.concatenate([w.reshape(-1) for w in Ws])
+    c = np.array([float(np.asarray(cc).reshape(-1)[-1]) if np.ndim(cc) else float(cc)
+                  for _, cc in linear_filters_cs], np.float64)
+    return W_cat, L, c, D
+
+
+class Bank:
+    """Device-resident template bank (tsr_bank): the tuple `linear_filters_cs` of
+    get_train_data.py:927-992, i.e. ((W_m f32 [L_m, F, K], c_m), ...)."""
+
+    def __init__(self, linear_filters_cs, ctx=None):
+        self.ctx = ctx or default_ctx()
+        W_cat, L, c, D = pack_filters(linear_filters_cs)
+        self.M, self.D, self.L, self.c = len(L), D, L, c
+        h = C.c_void_p()
+        check(lib().tsr_bank_create(self.ctx._h, ptr(W_cat), ptr(L), ptr(c), self.M, D, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tsr_bank_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def broadcast(self, root=0):
+        """RCCL broadcast of the bank from `root` to every rank (ctx.dist_init first)."""
+        check(lib().tsr_bank_broadcast(self.ctx._h, self._h, int(root)))
+
+    # ---- scoring ---------------------------------------------------------------------
+    def _offsets(self, feats, frame_offsets):
+        feats = np.ascontiguousarray(feats, dtype=np.uint8)
+        if frame_offsets is None:
+            frame_offsets = [0, feats.shape[0]]
+        offs = np.ascontiguousarray(frame_offsets, dtype=np.int64)
+        P = int(offs[-1])
+        if feats.size != P * self.D:
+            raise ValueError("feats has %d bytes, expected %d frames x D=%d" % (feats.size, P, self.D))
+        return feats, offs, P
+
+    def score(self, feats, frame_offsets=None, flags=TSR_EXACT):
+        """max_m(detect(E_n, W_m) + c_m) and the winning template id at every frame of
+        every utterance -> (scores f32 [sum T], ids i32 [sum T])."""
+        feats, offs, P = self._offsets(feats, frame_offsets)
+        scores = np.empty(P, np.float32)
+        ids = np.empty(P, np.int32)
+        check(lib().tsr_score_bank_u8(self.ctx._h, self._h, ptr(feats), ptr(offs), len(offs) - 1,
+                                      int(flags), ptr(scores), ptr(ids)))
+        return scores, ids
+
+    def score_all(self, feats, frame_offsets=None, flags=TSR_EXACT):
+        """detect(E_n, W_m) + c_m for every template -> f32 [M, sum T]."""
+        feats, offs, P = self._offsets(feats, frame_offsets)
+        out = np.empty((self.M, P), np.float32)
+        check(lib().tsr_score_bank_all_u8(self.ctx._h, self._h, ptr(feats), ptr(offs), len(offs) - 1,
+                                          int(flags), ptr(out)))
+        return out
+
+
+class Corpus:
+    """Utterances resident in HBM together with their score/id arrays (tsr_corpus)."""
+
+    def __init__(self, feats, frame_offsets, D=None, ctx=None):
+        self.ctx = ctx or default_ctx()
+        feats = np.ascontiguousarray(feats, dtype=np.uint8)
+        offs = np.ascontiguousarray(frame_offsets, dtype=np.int64)
+        P = int(offs[-1])
+        if D is None:
+            D = feats.size // max(P, 1)
+        if feats.size != P * D:
+            raise ValueError("feats has %d bytes, expected %d frames x D=%d" % (feats.size, P, D))
+        self.P, self.D, self.N = P, int(D), len(offs) - 1
+        h = C.c_void_p()
+        check(lib().tsr_corpus_create(self.ctx._h, ptr(feats), ptr(offs), self.N, self.D, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tsr_corpus_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def score(self, bank, flags=TSR_EXACT):
+        """Enqueue one scoring pass on the ctx stream (asynchronous)."""
+        check(lib().tsr_corpus_score(self.ctx._h, bank._h, self._h, int(flags)))
+
+    def download(self):
+        scores = np.empty(self.P, np.float32)
+        ids = np.empty(self.P, np.int32)
+        check(lib().tsr_corpus_download(self.ctx._h, self._h, ptr(scores), ptr(ids)))
+        return scores, ids
+
+
+class Parts:
+    """Device-resident part models of the patch coder (tsr_parts): logParts /
+    logInvParts of get_train_data.PartsParameters, f64 [K, P0, P1, E]."""
+
+    def __init__(self, log_parts, log_invparts, ctx=None):
+        self.ctx = ctx or default_ctx()
+        lp = np.ascontiguousarray(log_parts, dtype=np.float64)
+        lip = np.ascontiguousarray(log_invparts, dtype=np.float64)
+        if lp.ndim != 4 or lip.shape != lp.shape:
+            raise ValueError("log_parts/log_invparts must be [K, P0, P1, E] and equal-shaped")
+        self.K, self.P0, self.P1, self.E = lp.shape
+        h = C.c_void_p()
+        check(lib().tsr_parts_create(self.ctx._h, ptr(lp), ptr(lip), *lp.shape, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tsr_parts_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def features(self, X, threshold, spread=(0, 0), graph=None, grid=(1, 1), fast=False,
+                 return_argmax=False):
+        """code_parts[_fast] -> argmax -> spread -> [graph] -> [::g0, ::g1] on the GPU
+        (get_train_data.py:2619-2628 / :183-191) -> u8 [O0, O1, K]."""
+        X = np.ascontiguousarray(X, dtype=np.uint8)
+        if X.ndim != 3 or X.shape[2] != self.E:
+            raise ValueError("X must be [X0, X1, %d]" % self.E)
+        N0, N1 = X.shape[0] - self.P0 + 1, X.shape[1] - self.P1 + 1
+        g0, g1 = int(grid[0]), int(grid[1])
+        out = np.empty((-(-N0 // g0), -(-N1 // g1), self.K), np.uint8)
+        am = np.empty((N0, N1), np.int64) if return_argmax else None
+        g = None if graph is None else np.ascontiguousarray(graph, dtype=np.uint8)
+        if g is not None and g.shape != (self.K, self.K):
+            raise ValueError("part graph must be [K, K]")
+        check(lib().tsr_part_features(self.ctx._h, self._h, ptr(X), X.shape[0], X.shape[1],
+                                      int(threshold), int(bool(fast)), int(spread[0]), int(spread[1]),
+                                      ptr(g), g0, g1, ptr(out), ptr(am)))
+        return (out, am) if return_argmax else out
