@@ -18,18 +18,13 @@ namespace {
 
 constexpr int kThreads = 256;
 
-__device__ __forceinline__ uint32_t normalise01(uint32_t x)
-{
-    // byte-wise (b != 0) ? 1 : 0 without cross-byte carries
-    return ((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) >> 7) & 0x01010101u;
-}
-
 // One block = TB consecutive frame positions x (256/TB) template groups.
-// LDS holds rows [p0 + tau0, p0 + tau0 + TB + TC - 1) of the (0/1-normalised)
-// feature map, SD dwords per row (SD odd => conflict-free stride across lanes).
+// LDS holds rows [p0 + tau0, p0 + tau0 + TB + TC - 1) of the feature map (0/1
+// bytes, see corpus_pack_kernel), SD dwords per row (SD odd => conflict-free
+// stride across lanes).
 template <int TB>
 __global__ __launch_bounds__(kThreads) void exact_bank_kernel(
-    const uint8_t *__restrict__ X, int64_t P, int D, int Dq, int SD, int TC,
+    const uint8_t *__restrict__ X, int64_t P, int Dp, int Dq, int SD, int TC,
     const float *__restrict__ Wx, const int64_t *__restrict__ gx_off,
     const int32_t *__restrict__ gx_L, int n_groups, int M, float *__restrict__ raw)
 {
@@ -56,25 +51,16 @@ __global__ __launch_bounds__(kThreads) void exact_bank_kernel(
     for (int m = 0; m < TSR_MG; ++m) acc[m] = 0.0f;
 
     const int rows = TB + TC - 1;
-    const bool aligned = (D % 4) == 0;
+    const uint32_t *__restrict__ X4 = reinterpret_cast<const uint32_t *>(X);
+    const int Dp4 = Dp >> 2;
     for (int tau0 = 0; tau0 < Lblk; tau0 += TC) {
         __syncthreads();
-        // ---- stage rows [p0+tau0, p0+tau0+rows) -------------------------------
+        // ---- stage rows [p0+tau0, p0+tau0+rows): the corpus holds 0/1 bytes in rows of
+        //      Dp bytes (Dp % 16 == 0, zero padded), so whole dwords can be copied
         for (int idx = tid; idx < rows * SD; idx += kThreads) {
             const int r = idx / SD, i = idx - r * SD;
             const int64_t p = p0 + tau0 + r;
-            uint32_t v = 0;
-            if (p < P && i < Dq) {
-                const int64_t byte0 = p * D + 4 * (int64_t)i;
-                if (aligned) {
-                    v = *reinterpret_cast<const uint32_t *>(X + byte0);
-                } else {
-                    const int nb = min(4, D - 4 * i);
-                    for (int b = 0; b < nb; ++b) v |= (uint32_t)X[byte0 + b] << (8 * b);
-                }
-                v = normalise01(v);
-            }
-            lds[idx] = v;
+            lds[idx] = (p < P && i < Dq) ? X4[p * Dp4 + i] : 0u;
         }
         __syncthreads();
         // ---- accumulate taps tau0 .. min(tau0+TC, Lg) in reference order ---------
@@ -111,9 +97,9 @@ __global__ __launch_bounds__(kThreads) void exact_bank_kernel(
 // Fallback for feature rows too wide for the LDS tile: same order, rows read
 // straight from global memory (L1/L2 absorb the window overlap).
 __global__ __launch_bounds__(kThreads) void exact_bank_direct_kernel(
-    const uint8_t *__restrict__ X, int64_t P, int D, int Dq, const float *__restrict__ Wx,
-    const int64_t *__restrict__ gx_off, const int32_t *__restrict__ gx_L, int M,
-    float *__restrict__ raw)
+    const uint8_t *__restrict__ X, int64_t P, int D, int Dp, int Dq,
+    const float *__restrict__ Wx, const int64_t *__restrict__ gx_off,
+    const int32_t *__restrict__ gx_L, int M, float *__restrict__ raw)
 {
     const int g = blockIdx.y;
     const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
@@ -126,7 +112,7 @@ __global__ __launch_bounds__(kThreads) void exact_bank_direct_kernel(
         const int64_t row = p + tau;
         const float *__restrict__ w = Wg + (int64_t)tau * Dq * (TSR_MG * 4);
         for (int d = 0; d < D; ++d) {
-            const float x = (row < P && X[row * D + d]) ? 1.0f : 0.0f;
+            const float x = (row < P && X[row * Dp + d]) ? 1.0f : 0.0f;
             const float *__restrict__ wi = w + (d >> 2) * (TSR_MG * 4) + (d & 3);
 #pragma unroll
             for (int m = 0; m < TSR_MG; ++m) acc[m] = __builtin_fmaf(x, wi[4 * m], acc[m]);
@@ -211,7 +197,7 @@ __global__ __launch_bounds__(kThreads) void max_detect_examples_kernel(
 }  // namespace
 
 int tsr_launch_exact_bank(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *d_feats, int64_t P,
-                          float *d_raw)
+                          int Dp, float *d_raw)
 {
     if (P == 0) return TSR_OK;
     const int Dq = bank->Dq;
@@ -232,7 +218,7 @@ int tsr_launch_exact_bank(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *d_f
     if (TB == 0) {
         dim3 grid((unsigned)((P + kThreads - 1) / kThreads), bank->n_groups);
         hipLaunchKernelGGL(exact_bank_direct_kernel, grid, dim3(kThreads), 0, ctx->stream, d_feats, P,
-                           (int)bank->D, Dq, bank->d_Wx, d_gx_off, d_gx_L, bank->M, d_raw);
+                           (int)bank->D, Dp, Dq, bank->d_Wx, d_gx_off, d_gx_L, bank->M, d_raw);
         TSR_HIP(hipGetLastError());
         return TSR_OK;
     }
@@ -243,13 +229,13 @@ int tsr_launch_exact_bank(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *d_f
         TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(exact_bank_kernel<128>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(exact_bank_kernel<128>, grid, dim3(kThreads), lds, ctx->stream, d_feats, P,
-                           (int)bank->D, Dq, SD, TC, bank->d_Wx, d_gx_off, d_gx_L, bank->n_groups,
+                           Dp, Dq, SD, TC, bank->d_Wx, d_gx_off, d_gx_L, bank->n_groups,
                            bank->M, d_raw);
     } else {
         TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(exact_bank_kernel<64>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(exact_bank_kernel<64>, grid, dim3(kThreads), lds, ctx->stream, d_feats, P,
-                           (int)bank->D, Dq, SD, TC, bank->d_Wx, d_gx_off, d_gx_L, bank->n_groups,
+                           Dp, Dq, SD, TC, bank->d_Wx, d_gx_off, d_gx_L, bank->n_groups,
                            bank->M, d_raw);
     }
     TSR_HIP(hipGetLastError());
@@ -289,6 +275,40 @@ int tsr_launch_max_detect_examples(tsr_ctx *ctx, const uint8_t *d_F, int64_t N, 
     dim3 grid((unsigned)((T + kThreads - 1) / kThreads), (unsigned)N);
     hipLaunchKernelGGL(max_detect_examples_kernel, grid, dim3(kThreads), 0, ctx->stream, d_F, (int)N,
                        (int)T, (int)D, d_LF, (int)L, d_tmp);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+
+// Corpus upload: the caller's [P, D] bytes -> the resident form [P, Dp] with
+// Dp = round_up(D, 16), every byte normalised to (b != 0) and the row padding zeroed.
+// The reference tests `if F[...]` (compute_likelihood_linear_filter.pyx:168), so any
+// non-zero byte is an edge; normalising once here lets the scoring kernels use the
+// bytes directly as int8 / ubyte->float operands.
+namespace {
+__global__ __launch_bounds__(kThreads) void corpus_pack_kernel(const uint8_t *__restrict__ src,
+                                                               int64_t P, int D, int Dp,
+                                                               uint8_t *__restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;  // one dword of dst
+    const int Dp4 = Dp >> 2;
+    if (i >= P * Dp4) return;
+    const int64_t p = i / Dp4;
+    const int d0 = (int)(i - p * Dp4) * 4;
+    uint32_t v = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        if (d0 + b < D && src[p * D + d0 + b]) v |= 1u << (8 * b);
+    reinterpret_cast<uint32_t *>(dst)[i] = v;
+}
+}  // namespace
+
+int tsr_launch_corpus_pack(tsr_ctx *ctx, const uint8_t *d_src, int64_t P, int D, int Dp,
+                           uint8_t *d_dst)
+{
+    const int64_t n = P * (Dp >> 2);
+    if (n == 0) return TSR_OK;
+    hipLaunchKernelGGL(corpus_pack_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)),
+                       dim3(kThreads), 0, ctx->stream, d_src, P, D, Dp, d_dst);
     TSR_HIP(hipGetLastError());
     return TSR_OK;
 }

@@ -1,16 +1,564 @@
-// detect_mfma.hip -- MFMA (TSR_FAST) bank scorer.  Placeholder until the int8-limb
-// kernel lands: requests fall through to TSR_ERR_UNSUPPORTED so nothing silently
-// changes precision class.
+// detect_mfma.hip -- TSR_FAST: the template-bank scorer on the gfx950 matrix cores.
+//
+// What is computed (get_train_data.py:962-992 over compute_likelihood_linear_filter
+// .pyx:135-176):  score[p, m] = sum_{tau < L_m} sum_d X[p+tau, d] * W_m[tau, d].
+//
+// Formulation -- "skew GEMM".  G = X . Wall^T is one dense product with
+//     rows    = frames p of the whole corpus (utterances concatenated),
+//     K       = the D features of one frame,
+//     columns = every (template m, tap tau) pair, sum_m L_m of them,
+// and the window sum is the diagonal ("skew") reduction
+//     score[p, m] = sum_tau G[p + tau, (m, tau)].
+// No im2col, no padding of the bank to a common length, every frame is read once.
+//
+// Arithmetic -- exact integers.  X is {0,1} bytes, i.e. already an int8 operand.
+// Each template's f32 weights are quantised ONCE (bank build) to a 23-bit signed
+// fixed point with a per-template power-of-two scale and split into three signed
+// int8 limbs q = l2*65536 + l1*256 + l0.  Three v_mfma_i32_32x32x32_i8 per
+// K-block accumulate the limbs in int32; sums are exact, so the result does not
+// depend on tiling, wave count or summation order (bit-reproducible), and the only
+// deviation from the f32 reference is the weight quantisation (<= 2^-22 max|W_m|
+// per tap).  int8 MFMA runs at 2x the bf16 rate, so three limbs cost 1.5 bf16
+// passes -- cheaper than the two f16/bf16 limbs an equally safe float split needs.
+//
+// Data movement.
+//   * Weights are REGISTER-STATIONARY: a workgroup is 8 waves = CT column tiles
+//     (32 columns each) x KS K-slices; each wave keeps its NKB x 3 limb fragments
+//     (NKB*12 VGPRs) for the whole launch.  Config 2 (D=360, 8 x 32 taps): the
+//     entire bank, 288 KiB of limbs, lives in one workgroup's registers.
+//   * Frames stream through LDS in 32-row tiles by LDS-DMA (global_load_lds,
+//     16 B/lane), double buffered; the resident corpus rows are 16-byte multiples
+//     so a tile is one flat copy.  A-fragments are ds_read_b128, conflict-free
+//     because the row stride is an odd number of 16-byte slots.
+//   * The skew reduction goes through LDS atomics (ds_add_u32) into a small ring
+//     indexed by output frame; a finishing pass turns the ring into f32 scores,
+//     adds c_m, takes the max / first arg-max over templates and writes 8 bytes
+//     per frame.  HBM sees the feature map once and the result once.
+//
+// Roofline: MFMA-bound for M*L >~ 170 columns; algorithmic HBM
+// bytes per frame = D + 6.
+#include <math.h>
+
+#include <algorithm>
+
 #include "tsr_internal.h"
 
-int tsr_fast_bank_build(tsr_ctx *, tsr_bank *)
+namespace {
+
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+using i32x16 = __attribute__((ext_vector_type(16))) int;
+
+constexpr int kWaves = 8;
+constexpr int kThreads = kWaves * 64;
+constexpr int kMaxNKB = 12;   // K-blocks (of 32 features) a wave keeps in registers
+constexpr int kMaxSlots = 64; // template fragments per workgroup (ring rows)
+
+struct FastArgs {
+    const uint8_t *X;        // [P + slack][Dp] bytes in {0,1}
+    int Dp;                  // resident row stride (multiple of 16)
+    int SB;                  // LDS row stride: odd multiple of 16 >= Dp
+    int tile_bytes;          // bytes one LDS tile buffer holds (multiple of 1024)
+    int G, CT, KS;           // column groups; column tiles and K-slices per workgroup
+    int nseg;                // frame-stream segments (workgroups per column group)
+    const int32_t *seg;      // [3][nseg]: first output frame, end of outputs, end of rows
+    const i32x4 *Wl;         // limb fragments [G][CT][KS][NKB][3][64]
+    const int32_t *col_slot; // [G*CT*32] fragment slot of a column inside its group, -1 = padding
+    const int32_t *col_tau;  // [G*CT*32] tap index of the column inside its template
+    const int32_t *slot_tmpl;  // [G][kMaxSlots] template id of a slot (-1 = unused)
+    const int32_t *slot_frag;  // [G][kMaxSlots] row of raw_frag the slot writes (G > 1)
+    const double *t_inv_scale; // [M] 2^-e_m
+    const float *t_cf;         // [M] f32(c_m)
+    const int32_t *t_L;        // [M]
+    const int32_t *utt_end;    // [P]
+    int64_t P;
+    int ring;                // ring length in frames (power of two)
+    int lag;                 // tiles between emitting a tile and finishing it
+    float *scores;           // fused outputs (G == 1)
+    int32_t *ids;
+    float *all;              // [M][P] per-template scores (G == 1, optional)
+    float *raw_frag;         // [n_frag][P] partial raw scores (G > 1)
+};
+
+// LDS-DMA: 16 bytes per lane, LDS destination = wave-uniform base + lane*16.
+__device__ __forceinline__ void lds_dma16(const uint8_t *gsrc, uint8_t *lds_dst_wave_base)
 {
-    tsr_set_error("TSR_FAST: the MFMA path is not built into this library yet");
-    return TSR_ERR_UNSUPPORTED;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_dst_wave_base, 16, 0, 0);
 }
-void tsr_fast_bank_free(tsr_bank *) {}
-int tsr_launch_fast_bank(tsr_ctx *, const tsr_bank *, const uint8_t *, int64_t, const int32_t *,
-                         const int32_t *, int, float *, int32_t *, float *)
+
+template <int NKB>
+__global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a)
 {
-    return TSR_ERR_UNSUPPORTED;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = blockIdx.x % a.G;   // column group; neighbours share the same frames (L2 reuse)
+    const int sg = blockIdx.x / a.G;   // frame-stream segment
+    const int o0 = a.seg[sg], o1 = a.seg[a.nseg + sg], r1 = a.seg[2 * a.nseg + sg];
+    const int nOut = o1 - o0;
+    const int nT = (r1 - o0 + 31) >> 5;
+
+    // ---- LDS carve-up: [tile 0][tile 1][ring_lo][ring_hi] ------------------------------
+    uint8_t *xbuf0 = smem;
+    uint8_t *xbuf1 = smem + a.tile_bytes;
+    int *ring_lo = reinterpret_cast<int *>(smem + 2 * a.tile_bytes);
+    int *ring_hi = ring_lo + kMaxSlots * a.ring;
+    for (int i = tid; i < 2 * kMaxSlots * a.ring; i += kThreads) ring_lo[i] = 0;
+
+    // ---- this wave's role and its register-stationary limb fragments --------------------
+    const int ct = wave / a.KS, ks = wave - ct * a.KS;
+    const int coltile = cg * a.CT + ct;
+    i32x4 b[NKB][3];
+    {
+        const i32x4 *wl = a.Wl + ((size_t)(coltile * a.KS + ks) * NKB * 3) * 64 + lane;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) b[kb][l] = wl[(kb * 3 + l) * 64];
+    }
+    const int col = coltile * 32 + (lane & 31);
+    const int slot = a.col_slot[col];
+    // padding columns get a tap index that pushes every target frame out of range
+    const int tau = slot >= 0 ? a.col_tau[col] : (1 << 28);
+    const int rbase = (slot >= 0 ? slot : 0) * a.ring;
+    const int half = lane >> 5;
+    const int ring_mask = a.ring - 1;
+
+    // ---- frame tiles: tile t = rows [o0 + 32 t, +32), copied flat by LDS-DMA -------------
+    // one DMA instruction moves 1 KiB (64 lanes x 16 B); wave w issues pieces w, w+8, ...
+    const int n_pieces = a.tile_bytes >> 10;
+    const int slots_per_row = a.SB >> 4, src_slots = a.Dp >> 4;
+    auto stage = [&](int t, uint8_t *dst) {
+        const uint8_t *src_tile = a.X + ((int64_t)o0 + 32 * (int64_t)t) * a.Dp;
+        for (int pc = wave; pc < n_pieces; pc += kWaves) {
+            const int chunk = pc * 64 + lane;  // 16-byte slot of the LDS tile
+            const uint8_t *src;
+            if (slots_per_row == src_slots) {
+                src = src_tile + (int64_t)chunk * 16;
+            } else {  // LDS rows carry one extra (unused) slot to keep the stride odd
+                const int row = chunk / slots_per_row, c16 = chunk - row * slots_per_row;
+                src = src_tile + (int64_t)row * a.Dp + min(c16, src_slots - 1) * 16;
+            }
+            lds_dma16(src, dst + pc * 1024);
+        }
+    };
+
+    // A-fragment address of this lane: row (lane & 31), K-group (lane >> 5) of its K-slice
+    const int a_off = (lane & 31) * a.SB + half * 16 + ks * (NKB * 32);
+
+    auto finish_tile = [&](int f) {
+        // 32 output frames [32 f, 32 f + 32) of this segment: ring -> f32, + c, max/arg-max
+        const int prel = f * 32 + (lane & 31);
+        const bool valid = prel < nOut;
+        const int64_t p = (int64_t)o0 + prel;
+        const int ridx = prel & ring_mask;
+        const int uend = valid ? a.utt_end[p] : 0;
+        float best = -INFINITY;
+        int besti = 0x7fffffff;
+        const int32_t *st = a.slot_tmpl + cg * kMaxSlots;
+        for (int s = half; s < kMaxSlots; s += 2) {
+            const int m = st[s];
+            if (m < 0) break;  // slots are filled from 0 upwards
+            const int lo = ring_lo[s * a.ring + ridx], hi = ring_hi[s * a.ring + ridx];
+            ring_lo[s * a.ring + ridx] = 0;
+            ring_hi[s * a.ring + ridx] = 0;
+            const double v = ((double)hi * 65536.0 + (double)lo) * a.t_inv_scale[m];
+            if (a.raw_frag) {  // several column groups: partial sums, finished by the epilogue kernel
+                if (valid) a.raw_frag[(int64_t)a.slot_frag[cg * kMaxSlots + s] * a.P + p] = (float)v;
+            } else {
+                // tail t > T - L_m scores 0 (+ c_m), as the reference's zero tail does
+                const float raw = (p + a.t_L[m] <= uend) ? (float)v : 0.0f;
+                const float sc = raw + a.t_cf[m];
+                if (a.all && valid) a.all[(int64_t)m * a.P + p] = sc;
+                if (sc > best || (sc == best && m < besti)) {  // first maximum = lowest id
+                    best = sc;
+                    besti = m;
+                }
+            }
+        }
+        if (!a.raw_frag && a.scores) {
+            const float ob = __shfl_xor(best, 32);
+            const int oi = __shfl_xor(besti, 32);
+            if (ob > best || (ob == best && oi < besti)) {
+                best = ob;
+                besti = oi;
+            }
+            if (half == 0 && valid) {
+                a.scores[p] = best;
+                a.ids[p] = besti;
+            }
+        }
+    };
+
+    if (nT > 0) stage(0, xbuf0);
+    __syncthreads();  // (drains the DMA: hipcc waits vmcnt(0) before the barrier)
+
+    for (int t = 0; t < nT; ++t) {
+        uint8_t *cur = (t & 1) ? xbuf1 : xbuf0;
+        if (t + 1 < nT) stage(t + 1, (t & 1) ? xbuf0 : xbuf1);
+
+        // ---- 32 frames x 32 columns x (NKB*32) features, three limbs ---------------------
+        i32x16 acc0 = {}, acc1 = {}, acc2 = {};
+        const uint8_t *xa = cur + a_off;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const i32x4 av = *reinterpret_cast<const i32x4 *>(xa + kb * 32);
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b[kb][0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b[kb][1], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b[kb][2], acc2, 0, 0, 0);
+        }
+
+        // ---- skew reduction: G[row, (m, tau)] adds into frame row - tau of template m ------
+        // accumulator register r of lane (col, half) is row (r&3) + 8 (r>>2) + 4 half
+        const int pbase = t * 32 + 4 * half - tau;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int prel = pbase + (r & 3) + 8 * (r >> 2);
+            if ((unsigned)prel < (unsigned)nOut) {
+                const int idx = rbase + (prel & ring_mask);
+                atomicAdd(&ring_lo[idx], acc1[r] * 256 + acc0[r]);
+                atomicAdd(&ring_hi[idx], acc2[r]);
+            }
+        }
+        __syncthreads();  // tile t fully emitted; tile t+1 landed
+        const int f = t - a.lag;
+        if (f >= 0 && wave == (f & (kWaves - 1))) finish_tile(f);
+    }
+    const int nF = (nOut + 31) >> 5;
+    for (int f = max(nT - a.lag, 0) + wave; f < nF; f += kWaves) finish_tile(f);
+}
+
+// (G > 1) sum the fragments of every template, then the reference epilogue.
+__global__ __launch_bounds__(256) void frag_epilogue_kernel(
+    const float *__restrict__ raw_frag, int64_t P, int M, const int32_t *__restrict__ frag_first,
+    const int32_t *__restrict__ L, const float *__restrict__ cf,
+    const int32_t *__restrict__ utt_end, float *__restrict__ scores, int32_t *__restrict__ ids,
+    float *__restrict__ all)
+{
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int64_t end = utt_end[p];
+    float best = 0.0f;
+    int besti = 0;
+    for (int m = 0; m < M; ++m) {
+        float r = 0.0f;
+        for (int f = frag_first[m]; f < frag_first[m + 1]; ++f) r += raw_frag[(int64_t)f * P + p];
+        if (p + L[m] > end) r = 0.0f;
+        const float v = r + cf[m];
+        if (all) all[(int64_t)m * P + p] = v;
+        if (m == 0 || v > best) {
+            best = v;
+            besti = m;
+        }
+    }
+    if (scores) scores[p] = best;
+    if (ids) ids[p] = besti;
+}
+
+struct FastBank {
+    int NKB = 0, KS = 0, CT = 0, G = 0, nkb_total = 0, n_coltiles = 0, n_frag = 0;
+    i32x4 *d_Wl = nullptr;
+    int32_t *d_col_slot = nullptr, *d_col_tau = nullptr, *d_slot_tmpl = nullptr, *d_slot_frag = nullptr;
+    int32_t *d_frag_first = nullptr;
+    double *d_inv_scale = nullptr;
+};
+
+template <typename T>
+int upload(tsr_ctx *ctx, T **dptr, const std::vector<T> &v)
+{
+    *dptr = nullptr;
+    TSR_HIP(hipMalloc(reinterpret_cast<void **>(dptr), std::max<size_t>(v.size() * sizeof(T), 16)));
+    if (!v.empty()) TSR_HIP(hipMemcpyAsync(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return TSR_OK;
+}
+
+template <int NKB>
+int launch(tsr_ctx *ctx, const FastArgs &args, int grid, size_t lds)
+{
+    TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fast_bank_kernel<NKB>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fast_bank_kernel<NKB>, dim3(grid), dim3(kThreads), lds, ctx->stream, args);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+
+}  // namespace
+
+void tsr_fast_bank_free(tsr_bank *bank)
+{
+    FastBank *fb = static_cast<FastBank *>(bank->fast);
+    if (!fb) return;
+    (void)hipSetDevice(bank->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(fb->d_Wl);
+    (void)hipFree(fb->d_col_slot);
+    (void)hipFree(fb->d_col_tau);
+    (void)hipFree(fb->d_slot_tmpl);
+    (void)hipFree(fb->d_slot_frag);
+    (void)hipFree(fb->d_frag_first);
+    (void)hipFree(fb->d_inv_scale);
+    delete fb;
+    bank->fast = nullptr;
+}
+
+int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank)
+{
+    const int M = bank->M;
+    const int64_t D = bank->D;
+    const int nkb_total = (int)((D + 31) / 32);
+    int KS = 1;
+    while (KS < kWaves && (nkb_total + KS - 1) / KS > kMaxNKB) KS *= 2;
+    const int NKB = (nkb_total + KS - 1) / KS;
+    if (NKB > kMaxNKB) {
+        tsr_set_error("TSR_FAST: D=%lld needs more than %d K-blocks per wave", (long long)D, kMaxNKB);
+        return TSR_ERR_UNSUPPORTED;
+    }
+    const int CT = kWaves / KS;
+    const int64_t C = bank->sumL;
+    const int n_coltiles = (int)((C + 31) / 32);
+    const int G = (n_coltiles + CT - 1) / CT;
+
+    // ---- per-template power-of-two scale and the three int8 limbs --------------------------
+    std::vector<double> inv_scale(M);
+    std::vector<int8_t> limbs((size_t)3 * C * D);  // [limb][column][d]
+    std::vector<int32_t> col_tmpl((size_t)C), col_tau_v((size_t)C);
+    {
+        int64_t woff = 0, c0 = 0;
+        for (int m = 0; m < M; ++m) {
+            const int64_t n = (int64_t)bank->L[m] * D;
+            const float *w = bank->W_cat.data() + woff;
+            float mx = 0.0f;
+            for (int64_t i = 0; i < n; ++i) mx = std::max(mx, fabsf(w[i]));
+            int e = 0;
+            if (mx > 0.0f) {
+                int ex;
+                frexpf(mx, &ex);  // mx = f * 2^ex, f in [0.5, 1)  =>  mx * 2^(22-ex) in [2^21, 2^22)
+                e = 22 - ex;
+            }
+            const double s = ldexp(1.0, e);
+            inv_scale[m] = ldexp(1.0, -e);
+            for (int tau = 0; tau < bank->L[m]; ++tau) {
+                const int64_t c = c0 + tau;
+                col_tmpl[(size_t)c] = m;
+                col_tau_v[(size_t)c] = tau;
+                for (int64_t d = 0; d < D; ++d) {
+                    const int q = (int)llrint((double)w[tau * D + d] * s);  // |q| <= 2^22
+                    const int l0 = ((q + 128) & 255) - 128;
+                    const int q1 = (q - l0) >> 8;
+                    const int l1 = ((q1 + 128) & 255) - 128;
+                    const int l2 = (q1 - l1) >> 8;  // |l2| <= 65
+                    limbs[((size_t)0 * C + c) * D + d] = (int8_t)l0;
+                    limbs[((size_t)1 * C + c) * D + d] = (int8_t)l1;
+                    limbs[((size_t)2 * C + c) * D + d] = (int8_t)l2;
+                }
+            }
+            woff += n;
+            c0 += bank->L[m];
+        }
+    }
+    // ---- column groups -> fragment slots ------------------------------------------------------
+    const int64_t Cpad = (int64_t)G * CT * 32;
+    std::vector<int32_t> col_slot((size_t)Cpad, -1), col_tau((size_t)Cpad, 0);
+    std::vector<int32_t> slot_tmpl((size_t)G * kMaxSlots, -1), slot_frag((size_t)G * kMaxSlots, -1);
+    std::vector<std::vector<int>> frags_of(M);  // fragment ids per template, in column order
+    int n_frag = 0;
+    for (int g = 0; g < G; ++g) {
+        int nslots = 0, last_m = -1;
+        for (int64_t c = (int64_t)g * CT * 32; c < std::min<int64_t>(C, (int64_t)(g + 1) * CT * 32); ++c) {
+            const int m = col_tmpl[(size_t)c];
+            if (m != last_m) {
+                if (nslots == kMaxSlots) {
+                    tsr_set_error("TSR_FAST: more than %d templates share one column group", kMaxSlots);
+                    return TSR_ERR_UNSUPPORTED;
+                }
+                slot_tmpl[(size_t)g * kMaxSlots + nslots] = m;
+                slot_frag[(size_t)g * kMaxSlots + nslots] = n_frag;
+                frags_of[m].push_back(n_frag);
+                ++n_frag;
+                ++nslots;
+                last_m = m;
+            }
+            col_slot[(size_t)c] = nslots - 1;
+            col_tau[(size_t)c] = col_tau_v[(size_t)c];
+        }
+    }
+    // fragment ids are handed out in column order, so a template's fragments are consecutive
+    std::vector<int32_t> frag_first(M + 1, 0);
+    for (int m = 0; m < M; ++m) {
+        frag_first[m] = frags_of[m].front();
+        frag_first[m + 1] = frags_of[m].back() + 1;
+    }
+    // ---- limb fragments in register order: [coltile][ks][kb][limb][lane] x 16 bytes ------------
+    std::vector<i32x4> Wl((size_t)G * CT * KS * NKB * 3 * 64);
+    memset(Wl.data(), 0, Wl.size() * sizeof(i32x4));
+    for (int64_t tile = 0; tile < (int64_t)G * CT; ++tile)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int kb = 0; kb < NKB; ++kb)
+                for (int l = 0; l < 3; ++l)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int64_t c = tile * 32 + (lane & 31);
+                        if (c >= C) continue;
+                        int8_t *dst = reinterpret_cast<int8_t *>(
+                            &Wl[((((size_t)tile * KS + ks) * NKB + kb) * 3 + l) * 64 + lane]);
+                        const int64_t k0 = ((int64_t)ks * NKB + kb) * 32 + 16 * (lane >> 5);
+                        for (int e = 0; e < 16; ++e)
+                            if (k0 + e < D) dst[e] = limbs[((size_t)l * C + c) * D + k0 + e];
+                    }
+    FastBank *fb = new FastBank;
+    fb->NKB = NKB;
+    fb->KS = KS;
+    fb->CT = CT;
+    fb->G = G;
+    fb->nkb_total = nkb_total;
+    fb->n_coltiles = n_coltiles;
+    fb->n_frag = n_frag;
+    bank->fast = fb;
+    int s = upload(ctx, &fb->d_Wl, Wl);
+    if (s == TSR_OK) s = upload(ctx, &fb->d_col_slot, col_slot);
+    if (s == TSR_OK) s = upload(ctx, &fb->d_col_tau, col_tau);
+    if (s == TSR_OK) s = upload(ctx, &fb->d_slot_tmpl, slot_tmpl);
+    if (s == TSR_OK) s = upload(ctx, &fb->d_slot_frag, slot_frag);
+    if (s == TSR_OK) s = upload(ctx, &fb->d_frag_first, frag_first);
+    if (s == TSR_OK) s = upload(ctx, &fb->d_inv_scale, inv_scale);
+    if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
+    if (s != TSR_OK) tsr_fast_bank_free(bank);
+    return s;
+}
+
+// Partition the frame stream into `nseg` segments of near-equal length, cutting at
+// utterance boundaries when one is close (no halo needed there: windows never span
+// utterances) and inside an utterance otherwise (the segment then also reads the
+// Lmax-1 frames that its last windows overhang).
+static int build_plan(tsr_ctx *ctx, tsr_corpus *cp, int nseg, int Lmax)
+{
+    const int key = nseg * 65536 + Lmax;
+    if (cp->d_plan && cp->plan_key == key) return TSR_OK;
+    const int64_t P = cp->P;
+    std::vector<int32_t> plan((size_t)3 * nseg);
+    const double target = (double)P / nseg;
+    std::vector<int64_t> cuts(nseg + 1, 0);
+    cuts[nseg] = P;
+    const std::vector<int64_t> &off = cp->offsets;
+    for (int i = 1; i < nseg; ++i) {
+        const int64_t ideal = (int64_t)llrint(i * target);
+        auto it = std::lower_bound(off.begin(), off.end(), ideal);
+        int64_t best = -1;
+        if (it != off.end()) best = *it;
+        if (it != off.begin()) {
+            const int64_t lo = *(it - 1);
+            if (best < 0 || ideal - lo < best - ideal) best = lo;
+        }
+        // snap to an utterance boundary only when it is within ~1.5 tiles of the ideal cut:
+        // a halo costs one tile, an unbalanced segment costs the whole launch its excess
+        const bool near = best >= 0 && llabs(best - ideal) <= 48;
+        int64_t cut = near ? best : (ideal / 32) * 32;
+        cuts[i] = std::min<int64_t>(std::max(cut, cuts[i - 1]), P);
+    }
+    for (int i = 0; i < nseg; ++i) {
+        const int64_t o0 = cuts[i], o1 = cuts[i + 1];
+        const bool boundary = std::binary_search(off.begin(), off.end(), o1);
+        plan[(size_t)i] = (int32_t)o0;
+        plan[(size_t)nseg + i] = (int32_t)o1;
+        plan[(size_t)2 * nseg + i] = (int32_t)((o1 > o0 && !boundary) ? std::min<int64_t>(P, o1 + Lmax - 1) : o1);
+    }
+    if (cp->d_plan) {
+        TSR_HIP(hipStreamSynchronize(ctx->stream));
+        TSR_HIP(hipFree(cp->d_plan));
+        cp->d_plan = nullptr;
+    }
+    TSR_HIP(hipMalloc(reinterpret_cast<void **>(&cp->d_plan), plan.size() * 4));
+    TSR_HIP(hipMemcpyAsync(cp->d_plan, plan.data(), plan.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    cp->plan_key = key;
+    cp->plan_nseg = nseg;
+    return TSR_OK;
+}
+
+int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int flags,
+                         float *d_scores, int32_t *d_ids, float *d_all)
+{
+    (void)flags;
+    const FastBank *fb = static_cast<const FastBank *>(bank->fast);
+    if (!fb) return TSR_ERR_UNSUPPORTED;
+    const int64_t P = cp->P;
+    if (P == 0) return TSR_OK;
+    const int Dp = cp->Dp;
+    int SB = Dp;
+    if (((SB >> 4) & 1) == 0) SB += 16;  // odd number of 16-byte slots: conflict-free b128 reads
+    // a tile buffer: 32 rows, rounded up to whole 1 KiB DMA pieces, plus the bytes the last
+    // row's K-block reads may run past it (zero weights there, any finite byte is fine)
+    const int k_span = fb->KS * fb->NKB * 32;
+    int tile_bytes = 32 * SB + std::max(0, k_span + 16 - SB);
+    tile_bytes = (tile_bytes + 1023) / 1024 * 1024;
+    int lag = (bank->Lmax - 1 + 31) / 32;
+    int ring = 32;
+    while (ring < 32 * (lag + 2)) ring *= 2;
+    const size_t lds = (size_t)2 * tile_bytes + (size_t)2 * kMaxSlots * ring * 4;
+    if (lds > 160 * 1024) {
+        tsr_set_error("TSR_FAST: D=%lld, Lmax=%d need %zu bytes of LDS", (long long)bank->D, bank->Lmax, lds);
+        return TSR_ERR_UNSUPPORTED;
+    }
+    // segments: one workgroup per (segment, column group); one wave of workgroups per launch
+    int nseg = std::max(1, ctx->cus / fb->G);
+    const int64_t min_rows = 64;  // do not cut the stream finer than two tiles per segment
+    nseg = (int)std::max<int64_t>(1, std::min<int64_t>(nseg, (P + min_rows - 1) / min_rows));
+    TSR_TRY(build_plan(ctx, cp, nseg, bank->Lmax));
+
+    FastArgs a;
+    memset(&a, 0, sizeof a);
+    a.X = cp->d_feats;
+    a.Dp = Dp;
+    a.SB = SB;
+    a.tile_bytes = tile_bytes;
+    a.G = fb->G;
+    a.CT = fb->CT;
+    a.KS = fb->KS;
+    a.nseg = nseg;
+    a.seg = cp->d_plan;
+    a.Wl = fb->d_Wl;
+    a.col_slot = fb->d_col_slot;
+    a.col_tau = fb->d_col_tau;
+    a.slot_tmpl = fb->d_slot_tmpl;
+    a.slot_frag = fb->d_slot_frag;
+    a.t_inv_scale = fb->d_inv_scale;
+    a.t_cf = bank->d_cf;
+    a.t_L = bank->d_L;
+    a.utt_end = cp->d_utt_end;
+    a.P = P;
+    a.ring = ring;
+    a.lag = lag;
+    void *raw_frag = nullptr;
+    if (fb->G > 1) {
+        TSR_TRY(tsr_scratch(ctx, 0, (size_t)fb->n_frag * P * sizeof(float), &raw_frag));
+        a.raw_frag = (float *)raw_frag;
+    } else {
+        a.scores = d_scores;
+        a.ids = d_ids;
+        a.all = d_all;
+    }
+    const int grid = nseg * fb->G;
+    int s;
+    switch (fb->NKB) {
+    case 1: s = launch<1>(ctx, a, grid, lds); break;
+    case 2: s = launch<2>(ctx, a, grid, lds); break;
+    case 3: s = launch<3>(ctx, a, grid, lds); break;
+    case 4: s = launch<4>(ctx, a, grid, lds); break;
+    case 5: s = launch<5>(ctx, a, grid, lds); break;
+    case 6: s = launch<6>(ctx, a, grid, lds); break;
+    case 7: s = launch<7>(ctx, a, grid, lds); break;
+    case 8: s = launch<8>(ctx, a, grid, lds); break;
+    case 9: s = launch<9>(ctx, a, grid, lds); break;
+    case 10: s = launch<10>(ctx, a, grid, lds); break;
+    case 11: s = launch<11>(ctx, a, grid, lds); break;
+    default: s = launch<12>(ctx, a, grid, lds); break;
+    }
+    TSR_TRY(s);
+    if (fb->G > 1) {
+        hipLaunchKernelGGL(frag_epilogue_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0,
+                           ctx->stream, (const float *)raw_frag, P, bank->M, fb->d_frag_first, bank->d_L,
+                           bank->d_cf, cp->d_utt_end, d_scores, d_ids, d_all);
+        TSR_HIP(hipGetLastError());
+    }
+    return TSR_OK;
 }

@@ -292,7 +292,6 @@ TSR_API int tsr_bank_info(const tsr_bank *b, int32_t *M, int64_t *D, int32_t *Lm
 }
 
 // ---- corpus ---------------------------------------------------------------------
-static const size_t kFeatSlack = 64 * 1024;  // tiles may read (never use) past the end
 
 TSR_API int tsr_corpus_create(tsr_ctx *ctx, const uint8_t *feats, const int64_t *frame_offsets,
                               int64_t N, int64_t D, tsr_corpus **out)
@@ -321,7 +320,22 @@ TSR_API int tsr_corpus_create(tsr_ctx *ctx, const uint8_t *feats, const int64_t 
             ub[(size_t)p] = (int32_t)frame_offsets[n];
             ue[(size_t)p] = (int32_t)frame_offsets[n + 1];
         }
-    int s = dev_upload(ctx, &cp->d_feats, feats, (size_t)(P * D), kFeatSlack);
+    // resident form: 0/1 bytes, rows of Dp = round_up(D,16) bytes, zeroed slack behind the
+    // last row (tiles of the scoring kernels may read, never use, up to ~48 rows past it)
+    cp->Dp = (int)((D + 15) / 16 * 16);
+    const size_t body = (size_t)P * cp->Dp, slack = (size_t)48 * cp->Dp + 8192;
+    int s = TSR_OK;
+    if (hipMalloc(reinterpret_cast<void **>(&cp->d_feats), body + slack) != hipSuccess ||
+        hipMemsetAsync(cp->d_feats + body, 0, slack, ctx->stream) != hipSuccess) {
+        tsr_set_error("tsr_corpus_create: cannot allocate %zu bytes of device memory", body + slack);
+        s = TSR_ERR_HIP;
+    }
+    if (s == TSR_OK && P > 0) {
+        void *stage = nullptr;
+        s = tsr_scratch(ctx, SLOT_IN, (size_t)(P * D), &stage);
+        if (s == TSR_OK && hipMemcpyAsync(stage, feats, (size_t)(P * D), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
+        if (s == TSR_OK) s = tsr_launch_corpus_pack(ctx, (const uint8_t *)stage, P, (int)D, cp->Dp, cp->d_feats);
+    }
     if (s == TSR_OK) s = dev_upload(ctx, &cp->d_utt_beg, ub.data(), ub.size());
     if (s == TSR_OK) s = dev_upload(ctx, &cp->d_utt_end, ue.data(), ue.size());
     if (s == TSR_OK) s = dev_upload<float>(ctx, &cp->d_scores, nullptr, 0, (size_t)P * 4);
@@ -350,6 +364,7 @@ TSR_API int tsr_corpus_destroy(tsr_corpus *cp)
     dev_free(cp->d_utt_end);
     dev_free(cp->d_scores);
     dev_free(cp->d_ids);
+    dev_free(cp->d_plan);
     delete cp;
     return TSR_OK;
 }
@@ -370,13 +385,18 @@ static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp,
     if (cp->P == 0) return TSR_OK;
     TSR_HIP(hipSetDevice(ctx->device));
     if (flags & TSR_FAST) {
-        if (!bank->fast) TSR_TRY(tsr_fast_bank_build(ctx, const_cast<tsr_bank *>(bank)));
-        return tsr_launch_fast_bank(ctx, bank, cp->d_feats, cp->P, cp->d_utt_beg, cp->d_utt_end, flags,
-                                    d_all ? nullptr : cp->d_scores, d_all ? nullptr : cp->d_ids, d_all);
+        if (!bank->fast) {
+            int sb = tsr_fast_bank_build(ctx, const_cast<tsr_bank *>(bank));
+            if (sb != TSR_OK && sb != TSR_ERR_UNSUPPORTED) return sb;
+        }
+        int s = tsr_launch_fast_bank(ctx, bank, cp, flags, d_all ? nullptr : cp->d_scores,
+                                     d_all ? nullptr : cp->d_ids, d_all);
+        if (s != TSR_ERR_UNSUPPORTED) return s;
+        // geometry outside the MFMA kernel's envelope: the exact GPU kernel serves it
     }
     void *raw = nullptr;
     TSR_TRY(tsr_scratch(ctx, SLOT_RAW, (size_t)bank->M * cp->P * sizeof(float), &raw));
-    TSR_TRY(tsr_launch_exact_bank(ctx, bank, cp->d_feats, cp->P, (float *)raw));
+    TSR_TRY(tsr_launch_exact_bank(ctx, bank, cp->d_feats, cp->P, cp->Dp, (float *)raw));
     return tsr_launch_bank_epilogue(ctx, bank, (const float *)raw, cp->P, cp->d_utt_end, flags,
                                     d_all ? nullptr : cp->d_scores, d_all ? nullptr : cp->d_ids, d_all);
 }

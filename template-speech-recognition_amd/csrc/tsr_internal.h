@@ -95,12 +95,18 @@ struct tsr_corpus {
     tsr_ctx *ctx = nullptr;
     int device = 0;
     int64_t N = 0, D = 0, P = 0;     // P = total frames
-    uint8_t *d_feats = nullptr;      // [P, D] (+ slack so that tiles may over-read)
+    int Dp = 0;                      // resident row stride: round_up(D, 16)
+    uint8_t *d_feats = nullptr;      // [P, Dp] bytes in {0,1}, rows zero padded (+ zeroed slack
+                                     // behind the last row so that tiles may over-read)
     int32_t *d_utt_end = nullptr;    // [P] end frame (exclusive) of the utterance holding p
     int32_t *d_utt_beg = nullptr;    // [P] first frame of the utterance holding p
     float *d_scores = nullptr;       // [P]
     int32_t *d_ids = nullptr;        // [P]
     std::vector<int64_t> offsets;    // host [N+1]
+    // fast path: cached partition of the frame stream into per-workgroup segments
+    int plan_key = 0;                // (segments, Lmax) the plan was built for
+    int plan_nseg = 0;
+    int32_t *d_plan = nullptr;       // [3][nseg]: first output, end of outputs, end of rows
 };
 
 struct tsr_parts {
@@ -113,7 +119,9 @@ struct tsr_parts {
 // ---- kernels' host entry points (device pointers, enqueue on ctx->stream) -----
 // detect_exact.hip
 int tsr_launch_exact_bank(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *d_feats, int64_t P,
-                          float *d_raw /*[M][P]*/);
+                          int Dp, float *d_raw /*[M][P]*/);
+int tsr_launch_corpus_pack(tsr_ctx *ctx, const uint8_t *d_src, int64_t P, int D, int Dp,
+                           uint8_t *d_dst);
 int tsr_launch_bank_epilogue(tsr_ctx *ctx, const tsr_bank *bank, const float *d_raw, int64_t P,
                              const int32_t *d_utt_end, int flags, float *d_scores, int32_t *d_ids,
                              float *d_all /*[M][P] or null*/);
@@ -125,8 +133,7 @@ int tsr_launch_max_detect_examples(tsr_ctx *ctx, const uint8_t *d_F, int64_t N, 
 // detect_mfma.hip
 int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank);
 void tsr_fast_bank_free(tsr_bank *bank);
-int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *d_feats, int64_t P,
-                         const int32_t *d_utt_beg, const int32_t *d_utt_end, int flags,
+int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *corpus, int flags,
                          float *d_scores, int32_t *d_ids, float *d_all);
 // parts.hip
 int tsr_launch_code_parts(tsr_ctx *ctx, const tsr_parts *parts, const uint8_t *d_X, int64_t X0,
