@@ -43,6 +43,12 @@
 
 #include "tsr_internal.h"
 
+// Development ablation switches (never set in the shipped build): bit 0 drops the skew
+// emission, bit 1 the MFMAs, bit 2 the finishing pass, bit 3 the frame staging.
+#ifndef TSR_ABL
+#define TSR_ABL 0
+#endif
+
 namespace {
 
 using i32x4 = __attribute__((ext_vector_type(4))) int;
@@ -52,6 +58,15 @@ constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
 constexpr int kMaxNKB = 12;   // K-blocks (of 32 features) a wave keeps in registers
 constexpr int kMaxSlots = 64; // template fragments per workgroup (ring rows)
+
+struct SlotMeta {  // one template fragment handled by a workgroup (LDS copy, 32 bytes)
+    double inv_scale;  // 2^-e_m
+    float cf;          // f32(c_m)
+    int L;             // template length
+    int tmpl;          // template id
+    int frag;          // row of raw_frag this slot writes (G > 1)
+    int pad[2];
+};
 
 struct FastArgs {
     const uint8_t *X;        // [P + slack][Dp] bytes in {0,1}
@@ -64,12 +79,9 @@ struct FastArgs {
     const i32x4 *Wl;         // limb fragments [G][CT][KS][NKB][3][64]
     const int32_t *col_slot; // [G*CT*32] fragment slot of a column inside its group, -1 = padding
     const int32_t *col_tau;  // [G*CT*32] tap index of the column inside its template
-    const int32_t *slot_tmpl;  // [G][kMaxSlots] template id of a slot (-1 = unused)
-    const int32_t *slot_frag;  // [G][kMaxSlots] row of raw_frag the slot writes (G > 1)
-    const double *t_inv_scale; // [M] 2^-e_m
-    const float *t_cf;         // [M] f32(c_m)
-    const int32_t *t_L;        // [M]
-    const int32_t *utt_end;    // [P]
+    const SlotMeta *slots;   // [G][kMaxSlots]
+    const int32_t *g_nslots; // [G] slots in use per column group
+    const int32_t *utt_end;  // [P]
     int64_t P;
     int ring;                // ring length in frames (power of two)
     int lag;                 // tiles between emitting a tile and finishing it
@@ -79,12 +91,37 @@ struct FastArgs {
     float *raw_frag;         // [n_frag][P] partial raw scores (G > 1)
 };
 
-// LDS-DMA: 16 bytes per lane, LDS destination = wave-uniform base + lane*16.
-__device__ __forceinline__ void lds_dma16(const uint8_t *gsrc, uint8_t *lds_dst_wave_base)
+// LDS-DMA (global_load_lds): `size` bytes per lane straight into LDS, destination =
+// wave-uniform LDS byte address + lane*size, no VGPR round trip.  Issued through inline asm
+// on purpose: hipcc does not model an asm statement's memory operation, so it neither
+// drains the DMA (s_waitcnt vmcnt(0)) in front of the next ds_read -- it cannot prove that
+// the tile being filled is not the tile being read -- nor counts it in its own waits.  The
+// kernel drains explicitly (dma_drain) in front of the barrier that publishes the tile.
+// M0 carries the LDS address and is saved/restored inside the statement
+// (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ unsigned lds_addr(const void *p)
 {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                     (__attribute__((address_space(3))) void *)lds_dst_wave_base, 16, 0, 0);
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char *)p;
 }
+__device__ __forceinline__ void lds_dma16(const uint8_t *gsrc, unsigned lds_dst_wave_base)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst_wave_base)
+                 : "memory");
+}
+__device__ __forceinline__ void lds_dma4(const void *gsrc, unsigned lds_dst_wave_base)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst_wave_base)
+                 : "memory");
+}
+__device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int NKB>
 __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a)
@@ -98,13 +135,17 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
     const int o0 = a.seg[sg], o1 = a.seg[a.nseg + sg], r1 = a.seg[2 * a.nseg + sg];
     const int nOut = o1 - o0;
     const int nT = (r1 - o0 + 31) >> 5;
+    const int nslots = a.g_nslots[cg];
 
-    // ---- LDS carve-up: [tile 0][tile 1][ring_lo][ring_hi] ------------------------------
+    // ---- LDS carve-up: [tile 0][tile 1][slot meta][utt_end ring][ring: (nslots+1) x int64] ---
     uint8_t *xbuf0 = smem;
     uint8_t *xbuf1 = smem + a.tile_bytes;
-    int *ring_lo = reinterpret_cast<int *>(smem + 2 * a.tile_bytes);
-    int *ring_hi = ring_lo + kMaxSlots * a.ring;
-    for (int i = tid; i < 2 * kMaxSlots * a.ring; i += kThreads) ring_lo[i] = 0;
+    SlotMeta *meta = reinterpret_cast<SlotMeta *>(smem + 2 * a.tile_bytes);
+    int *uend_ring = reinterpret_cast<int *>(meta + kMaxSlots);  // utt_end of the frames in flight
+    long long *ring = reinterpret_cast<long long *>(uend_ring + a.ring + 64);
+    const int dummy = nslots * a.ring;  // out-of-range emissions land here, never read
+    for (int i = tid; i < (nslots + 1) * a.ring; i += kThreads) ring[i] = 0;
+    if (tid < nslots) meta[tid] = a.slots[cg * kMaxSlots + tid];
 
     // ---- this wave's role and its register-stationary limb fragments --------------------
     const int ct = wave / a.KS, ks = wave - ct * a.KS;
@@ -130,6 +171,7 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
     const int n_pieces = a.tile_bytes >> 10;
     const int slots_per_row = a.SB >> 4, src_slots = a.Dp >> 4;
     auto stage = [&](int t, uint8_t *dst) {
+        if (TSR_ABL & 8) return;
         const uint8_t *src_tile = a.X + ((int64_t)o0 + 32 * (int64_t)t) * a.Dp;
         for (int pc = wave; pc < n_pieces; pc += kWaves) {
             const int chunk = pc * 64 + lane;  // 16-byte slot of the LDS tile
@@ -140,93 +182,182 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
                 const int row = chunk / slots_per_row, c16 = chunk - row * slots_per_row;
                 src = src_tile + (int64_t)row * a.Dp + min(c16, src_slots - 1) * 16;
             }
-            lds_dma16(src, dst + pc * 1024);
+            lds_dma16(src, __builtin_amdgcn_readfirstlane(lds_addr(dst) + pc * 1024));
         }
+        // the utt_end values of the tile's 32 frames ride along (4-byte DMA, one wave): the
+        // finishing pass must not issue register loads, or hipcc drains the tile DMA early
+        if (wave == kWaves - 1 && lane < 32)
+            lds_dma4(a.utt_end + (int64_t)o0 + 32 * (int64_t)t + lane,
+                     __builtin_amdgcn_readfirstlane(lds_addr(uend_ring + ((32 * t) & ring_mask))));
     };
 
     // A-fragment address of this lane: row (lane & 31), K-group (lane >> 5) of its K-slice
     const int a_off = (lane & 31) * a.SB + half * 16 + ks * (NKB * 32);
 
-    auto finish_tile = [&](int f) {
-        // 32 output frames [32 f, 32 f + 32) of this segment: ring -> f32, + c, max/arg-max
-        const int prel = f * 32 + (lane & 31);
-        const bool valid = prel < nOut;
-        const int64_t p = (int64_t)o0 + prel;
-        const int ridx = prel & ring_mask;
-        const int uend = valid ? a.utt_end[p] : 0;
-        float best = -INFINITY;
-        int besti = 0x7fffffff;
-        const int32_t *st = a.slot_tmpl + cg * kMaxSlots;
-        for (int s = half; s < kMaxSlots; s += 2) {
-            const int m = st[s];
-            if (m < 0) break;  // slots are filled from 0 upwards
-            const int lo = ring_lo[s * a.ring + ridx], hi = ring_hi[s * a.ring + ridx];
-            ring_lo[s * a.ring + ridx] = 0;
-            ring_hi[s * a.ring + ridx] = 0;
-            const double v = ((double)hi * 65536.0 + (double)lo) * a.t_inv_scale[m];
-            if (a.raw_frag) {  // several column groups: partial sums, finished by the epilogue kernel
-                if (valid) a.raw_frag[(int64_t)a.slot_frag[cg * kMaxSlots + s] * a.P + p] = (float)v;
-            } else {
-                // tail t > T - L_m scores 0 (+ c_m), as the reference's zero tail does
-                const float raw = (p + a.t_L[m] <= uend) ? (float)v : 0.0f;
-                const float sc = raw + a.t_cf[m];
-                if (a.all && valid) a.all[(int64_t)m * a.P + p] = sc;
-                if (sc > best || (sc == best && m < besti)) {  // first maximum = lowest id
-                    best = sc;
-                    besti = m;
+    // Finishing pass for one of this lane's frames.  32 frames per tile are spread over the
+    // whole workgroup: wave w takes frames 4w..4w+3, the 16 lanes of a frame (one DPP row)
+    // take slots lane%16 (+16, ...).  Split in three phases so that tile_step can issue them
+    // between MFMAs: (A) LDS reads + ring reset, (B) int64 -> f32 score, (C) max / first
+    // arg-max across the 16 lanes by DPP row rotations + the 8-byte result store.
+    const int fr_in_tile = 4 * wave + (lane >> 4);
+    struct Fin {
+        long long q;
+        SlotMeta sm;
+        int uend, prel;
+        float best;
+        int besti;
+    };
+    auto fin_a = [&](Fin &fs, int f, int s) {
+        fs.prel = f * 32 + fr_in_tile;
+        const int ridx = fs.prel & ring_mask;
+        fs.uend = uend_ring[ridx];
+        fs.sm = meta[min(s, kMaxSlots - 1)];
+        long long *cell = &ring[(s < nslots ? s : nslots) * a.ring + ridx];  // spare row when idle
+        fs.q = *cell;
+        *cell = 0;
+    };
+    auto fin_b = [&](Fin &fs, int s) {
+        const bool valid = fs.prel < nOut && s < nslots;
+        const int64_t p = (int64_t)o0 + fs.prel;
+        const double x = (double)fs.q * fs.sm.inv_scale;
+        if (a.raw_frag) {  // several column groups: partial sums, finished by the epilogue kernel
+            if (valid) a.raw_frag[(int64_t)fs.sm.frag * a.P + p] = (float)x;
+            return;
+        }
+        // tail t > T - L_m scores 0 (+ c_m), as the reference's zero tail does
+        const float raw = (p + fs.sm.L <= fs.uend) ? (float)x : 0.0f;
+        const float sc = raw + fs.sm.cf;
+        if (a.all && valid) a.all[(int64_t)fs.sm.tmpl * a.P + p] = sc;
+        if (s < nslots && (sc > fs.best || (sc == fs.best && fs.sm.tmpl < fs.besti))) {
+            fs.best = sc;  // first maximum = lowest template id
+            fs.besti = fs.sm.tmpl;
+        }
+    };
+    auto fin_c = [&](Fin &fs) {
+        if (a.raw_frag || !a.scores) return;
+#define TSR_DPP_STEP(ctrl)                                                                        \
+    {                                                                                             \
+        const float ob = __builtin_bit_cast(                                                      \
+            float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, fs.best), ctrl, 0xf, 0xf, false)); \
+        const int oi = __builtin_amdgcn_update_dpp(0, fs.besti, ctrl, 0xf, 0xf, false);           \
+        if (ob > fs.best || (ob == fs.best && oi < fs.besti)) {                                   \
+            fs.best = ob;                                                                         \
+            fs.besti = oi;                                                                        \
+        }                                                                                         \
+    }
+        TSR_DPP_STEP(0x128)  // row_ror:8
+        TSR_DPP_STEP(0x124)  // row_ror:4
+        TSR_DPP_STEP(0x122)  // row_ror:2
+        TSR_DPP_STEP(0x121)  // row_ror:1
+#undef TSR_DPP_STEP
+        if ((lane & 15) == 0 && fs.prel < nOut) {
+            const int64_t p = (int64_t)o0 + fs.prel;
+            a.scores[p] = fs.best;
+            a.ids[p] = fs.besti;
+        }
+    };
+    auto finish_tile = [&](int f) {  // stand-alone form (pipeline drain, > 16 slots)
+        if (TSR_ABL & 4) return;
+        Fin fs;
+        fs.best = -INFINITY;
+        fs.besti = 0x7fffffff;
+        for (int s = lane & 15; s < ((nslots + 15) & ~15); s += 16) {
+            fin_a(fs, f, s);
+            fin_b(fs, s);
+        }
+        fin_c(fs);
+    };
+
+    // One tile step: 32 frames x 32 columns x (NKB*32) features in three limbs (36 MFMAs at
+    // NKB = 12) -> one exact int32 per element in vn (|sum| <= NKB*32 * 2^22 < 2^31, weights
+    // are quantised to |q| <= 2^22), WHILE the previous tile's sums `v` go through the skew
+    // reduction -- G[row, (m, tau)] adds into frame row - tau of its template (ring, LDS
+    // atomics) -- and an older tile `fin` is finished.  Emission and finishing are spread
+    // over the K-block steps so that their VALU and LDS work issues in the shadow of the
+    // MFMAs; sched_barrier keeps hipcc from clustering them behind the last MFMA.
+    // Accumulator register r of lane (col, half) is row (r&3) + 8 (r>>2) + 4 half.  No
+    // branches: out-of-range targets go to the spare ring row.
+    auto tile_step = [&](const uint8_t *xt, i32x16 &vn, bool do_mfma, int te, const i32x16 &v,
+                         bool do_emit, int fin, bool do_fin) {
+        i32x16 acc0 = {}, acc1 = {}, acc2 = {};
+        const uint8_t *xa = xt + a_off;
+        const int pbase = te * 32 + 4 * half - tau;
+        Fin fs;
+        fs.best = -INFINITY;
+        fs.besti = 0x7fffffff;
+        constexpr int kA = 0, kB = (NKB * 2) / 5, kC = (NKB * 3) / 5;  // steps of the finish phases
+        i32x4 av = *reinterpret_cast<const i32x4 *>(xa);
+        i32x4 av1 = av;
+        if (NKB > 1) av1 = *reinterpret_cast<const i32x4 *>(xa + 32);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            i32x4 av2 = av1;  // A fragments are fetched two K-blocks ahead of their MFMAs
+            if (kb + 2 < NKB) av2 = *reinterpret_cast<const i32x4 *>(xa + (kb + 2) * 32);
+            if (do_mfma) {
+                if (TSR_ABL & 2) {
+                    asm volatile("" ::"v"(av), "v"(b[kb][0]), "v"(b[kb][1]), "v"(b[kb][2]));
+                } else {
+                    acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b[kb][0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b[kb][1], acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b[kb][2], acc2, 0, 0, 0);
                 }
             }
+            if (do_emit && !(TSR_ABL & 1)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (r * NKB / 16 != kb) continue;  // compile-time after unrolling
+                    const int prel = pbase + (r & 3) + 8 * (r >> 2);
+                    const int idx = (((unsigned)prel < (unsigned)nOut) ? rbase : dummy) + (prel & ring_mask);
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&ring[idx]),
+                              (unsigned long long)(long long)v[r]);
+                }
+            }
+            if (do_fin && !(TSR_ABL & 4)) {
+                if (kb == kA) fin_a(fs, fin, lane & 15);
+                if (kb == kB) fin_b(fs, lane & 15);
+                if (kb == kC) fin_c(fs);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            av = av1;
+            av1 = av2;
         }
-        if (!a.raw_frag && a.scores) {
-            const float ob = __shfl_xor(best, 32);
-            const int oi = __shfl_xor(besti, 32);
-            if (ob > best || (ob == best && oi < besti)) {
-                best = ob;
-                besti = oi;
-            }
-            if (half == 0 && valid) {
-                a.scores[p] = best;
-                a.ids[p] = besti;
-            }
+        if (TSR_ABL & 3) asm volatile("" : "+v"(acc0), "+v"(acc1), "+v"(acc2));
+        if (do_mfma) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) vn[r] = (acc2[r] * 256 + acc1[r]) * 256 + acc0[r];
         }
     };
 
+    // ---- software pipeline: MFMA(t) runs beside the emission of tile t-1 and the finishing
+    //      of tile t - lag (one barrier per tile) ------------------------------------------
+    // finish(f) needs every tile up to f + a.lag emitted; emission(t-1) is only complete at
+    // the barrier that ends iteration t, so iteration t may finish f = t - a.lag - 2.
+    const int lag = a.lag + 2;
+    const bool inl = nslots <= 16;  // finishing pass rides inside tile_step
+    i32x16 v = {};
     if (nT > 0) stage(0, xbuf0);
-    __syncthreads();  // (drains the DMA: hipcc waits vmcnt(0) before the barrier)
-
-    for (int t = 0; t < nT; ++t) {
-        uint8_t *cur = (t & 1) ? xbuf1 : xbuf0;
-        if (t + 1 < nT) stage(t + 1, (t & 1) ? xbuf0 : xbuf1);
-
-        // ---- 32 frames x 32 columns x (NKB*32) features, three limbs ---------------------
-        i32x16 acc0 = {}, acc1 = {}, acc2 = {};
-        const uint8_t *xa = cur + a_off;
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-            const i32x4 av = *reinterpret_cast<const i32x4 *>(xa + kb * 32);
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b[kb][0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b[kb][1], acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b[kb][2], acc2, 0, 0, 0);
-        }
-
-        // ---- skew reduction: G[row, (m, tau)] adds into frame row - tau of template m ------
-        // accumulator register r of lane (col, half) is row (r&3) + 8 (r>>2) + 4 half
-        const int pbase = t * 32 + 4 * half - tau;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int prel = pbase + (r & 3) + 8 * (r >> 2);
-            if ((unsigned)prel < (unsigned)nOut) {
-                const int idx = rbase + (prel & ring_mask);
-                atomicAdd(&ring_lo[idx], acc1[r] * 256 + acc0[r]);
-                atomicAdd(&ring_hi[idx], acc2[r]);
-            }
-        }
-        __syncthreads();  // tile t fully emitted; tile t+1 landed
-        const int f = t - a.lag;
-        if (f >= 0 && wave == (f & (kWaves - 1))) finish_tile(f);
+    dma_drain();
+    __syncthreads();  // ring/meta initialised, tile 0 landed
+    if (nT > 0) {
+        if (nT > 1) stage(1, xbuf1);
+        tile_step(xbuf0, v, true, 0, v, false, 0, false);
+        dma_drain();
+        __syncthreads();
     }
+    for (int t = 1; t < nT; ++t) {
+        if (t + 1 < nT) stage(t + 1, (t & 1) ? xbuf0 : xbuf1);
+        i32x16 vn;
+        const int f = t - lag;
+        tile_step((t & 1) ? xbuf1 : xbuf0, vn, true, t - 1, v, true, f, inl && f >= 0);
+        v = vn;
+        if (!inl && f >= 0) finish_tile(f);
+        dma_drain();
+        __syncthreads();  // tile t-1 fully emitted; tile t+1 landed
+    }
+    if (nT > 0) tile_step(xbuf0, v, false, nT - 1, v, true, 0, false);
+    __syncthreads();
     const int nF = (nOut + 31) >> 5;
-    for (int f = max(nT - a.lag, 0) + wave; f < nF; f += kWaves) finish_tile(f);
+    for (int f = max(nT - lag, 0); f < nF; ++f) finish_tile(f);
 }
 
 // (G > 1) sum the fragments of every template, then the reference epilogue.
@@ -259,9 +390,10 @@ __global__ __launch_bounds__(256) void frag_epilogue_kernel(
 struct FastBank {
     int NKB = 0, KS = 0, CT = 0, G = 0, nkb_total = 0, n_coltiles = 0, n_frag = 0;
     i32x4 *d_Wl = nullptr;
-    int32_t *d_col_slot = nullptr, *d_col_tau = nullptr, *d_slot_tmpl = nullptr, *d_slot_frag = nullptr;
+    int32_t *d_col_slot = nullptr, *d_col_tau = nullptr, *d_g_nslots = nullptr;
     int32_t *d_frag_first = nullptr;
-    double *d_inv_scale = nullptr;
+    SlotMeta *d_slots = nullptr;
+    int max_slots = 0;
 };
 
 template <typename T>
@@ -294,10 +426,9 @@ void tsr_fast_bank_free(tsr_bank *bank)
     (void)hipFree(fb->d_Wl);
     (void)hipFree(fb->d_col_slot);
     (void)hipFree(fb->d_col_tau);
-    (void)hipFree(fb->d_slot_tmpl);
-    (void)hipFree(fb->d_slot_frag);
+    (void)hipFree(fb->d_g_nslots);
     (void)hipFree(fb->d_frag_first);
-    (void)hipFree(fb->d_inv_scale);
+    (void)hipFree(fb->d_slots);
     delete fb;
     bank->fast = nullptr;
 }
@@ -360,7 +491,10 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank)
     // ---- column groups -> fragment slots ------------------------------------------------------
     const int64_t Cpad = (int64_t)G * CT * 32;
     std::vector<int32_t> col_slot((size_t)Cpad, -1), col_tau((size_t)Cpad, 0);
-    std::vector<int32_t> slot_tmpl((size_t)G * kMaxSlots, -1), slot_frag((size_t)G * kMaxSlots, -1);
+    std::vector<SlotMeta> slots((size_t)G * kMaxSlots);
+    memset(slots.data(), 0, slots.size() * sizeof(SlotMeta));
+    std::vector<int32_t> g_nslots(G, 0);
+    int max_slots = 0;
     std::vector<std::vector<int>> frags_of(M);  // fragment ids per template, in column order
     int n_frag = 0;
     for (int g = 0; g < G; ++g) {
@@ -372,8 +506,12 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank)
                     tsr_set_error("TSR_FAST: more than %d templates share one column group", kMaxSlots);
                     return TSR_ERR_UNSUPPORTED;
                 }
-                slot_tmpl[(size_t)g * kMaxSlots + nslots] = m;
-                slot_frag[(size_t)g * kMaxSlots + nslots] = n_frag;
+                SlotMeta &sm = slots[(size_t)g * kMaxSlots + nslots];
+                sm.inv_scale = inv_scale[m];
+                sm.cf = (float)bank->c[m];
+                sm.L = bank->L[m];
+                sm.tmpl = m;
+                sm.frag = n_frag;
                 frags_of[m].push_back(n_frag);
                 ++n_frag;
                 ++nslots;
@@ -382,6 +520,8 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank)
             col_slot[(size_t)c] = nslots - 1;
             col_tau[(size_t)c] = col_tau_v[(size_t)c];
         }
+        g_nslots[g] = nslots;
+        max_slots = std::max(max_slots, nslots);
     }
     // fragment ids are handed out in column order, so a template's fragments are consecutive
     std::vector<int32_t> frag_first(M + 1, 0);
@@ -413,14 +553,14 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank)
     fb->nkb_total = nkb_total;
     fb->n_coltiles = n_coltiles;
     fb->n_frag = n_frag;
+    fb->max_slots = max_slots;
     bank->fast = fb;
     int s = upload(ctx, &fb->d_Wl, Wl);
     if (s == TSR_OK) s = upload(ctx, &fb->d_col_slot, col_slot);
     if (s == TSR_OK) s = upload(ctx, &fb->d_col_tau, col_tau);
-    if (s == TSR_OK) s = upload(ctx, &fb->d_slot_tmpl, slot_tmpl);
-    if (s == TSR_OK) s = upload(ctx, &fb->d_slot_frag, slot_frag);
+    if (s == TSR_OK) s = upload(ctx, &fb->d_g_nslots, g_nslots);
     if (s == TSR_OK) s = upload(ctx, &fb->d_frag_first, frag_first);
-    if (s == TSR_OK) s = upload(ctx, &fb->d_inv_scale, inv_scale);
+    if (s == TSR_OK) s = upload(ctx, &fb->d_slots, slots);
     if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
     if (s != TSR_OK) tsr_fast_bank_free(bank);
     return s;
@@ -491,10 +631,14 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
     const int k_span = fb->KS * fb->NKB * 32;
     int tile_bytes = 32 * SB + std::max(0, k_span + 16 - SB);
     tile_bytes = (tile_bytes + 1023) / 1024 * 1024;
+    // a frame is final once the tile holding its last tap (Lmax-1 rows further) is emitted;
+    // emission trails the MFMAs by one tile and finishing trails emission by one barrier,
+    // hence the ring spans lag + 4 tiles
     int lag = (bank->Lmax - 1 + 31) / 32;
     int ring = 32;
-    while (ring < 32 * (lag + 2)) ring *= 2;
-    const size_t lds = (size_t)2 * tile_bytes + (size_t)2 * kMaxSlots * ring * 4;
+    while (ring < 32 * (lag + 4)) ring *= 2;
+    const size_t lds = (size_t)2 * tile_bytes + (size_t)kMaxSlots * sizeof(SlotMeta) +
+                       (size_t)(ring + 64) * 4 + (size_t)(fb->max_slots + 1) * ring * 8;
     if (lds > 160 * 1024) {
         tsr_set_error("TSR_FAST: D=%lld, Lmax=%d need %zu bytes of LDS", (long long)bank->D, bank->Lmax, lds);
         return TSR_ERR_UNSUPPORTED;
@@ -519,11 +663,8 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
     a.Wl = fb->d_Wl;
     a.col_slot = fb->d_col_slot;
     a.col_tau = fb->d_col_tau;
-    a.slot_tmpl = fb->d_slot_tmpl;
-    a.slot_frag = fb->d_slot_frag;
-    a.t_inv_scale = fb->d_inv_scale;
-    a.t_cf = bank->d_cf;
-    a.t_L = bank->d_L;
+    a.slots = fb->d_slots;
+    a.g_nslots = fb->d_g_nslots;
     a.utt_end = cp->d_utt_end;
     a.P = P;
     a.ring = ring;

@@ -337,7 +337,7 @@ TSR_API int tsr_corpus_create(tsr_ctx *ctx, const uint8_t *feats, const int64_t 
         if (s == TSR_OK) s = tsr_launch_corpus_pack(ctx, (const uint8_t *)stage, P, (int)D, cp->Dp, cp->d_feats);
     }
     if (s == TSR_OK) s = dev_upload(ctx, &cp->d_utt_beg, ub.data(), ub.size());
-    if (s == TSR_OK) s = dev_upload(ctx, &cp->d_utt_end, ue.data(), ue.size());
+    if (s == TSR_OK) s = dev_upload(ctx, &cp->d_utt_end, ue.data(), ue.size(), 256 * sizeof(int32_t));  // zeroed slack: tiles read past P
     if (s == TSR_OK) s = dev_upload<float>(ctx, &cp->d_scores, nullptr, 0, (size_t)P * 4);
     if (s == TSR_OK) s = dev_upload<int32_t>(ctx, &cp->d_ids, nullptr, 0, (size_t)P * 4);
     if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {

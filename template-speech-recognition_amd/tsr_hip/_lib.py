@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "lib", "libtsr_hip.so")
+LIB_PATH = os.environ.get("TSR_HIP_LIB") or os.path.join(_PKG, "lib", "libtsr_hip.so")
 
 TSR_OK, TSR_ERR_INVALID, TSR_ERR_HIP, TSR_ERR_NO_DEVICE, TSR_ERR_UNSUPPORTED, TSR_ERR_NONFINITE, \
     TSR_ERR_RCCL = range(7)
