@@ -48,15 +48,15 @@ enum {
  *   TSR_EXACT: f32 accumulation in the reference's order tau -> f -> k
  *              (compute_likelihood_linear_filter.pyx:162-175); raw scores are
  *              bit-identical to the Cython path.
- *   TSR_FAST : MFMA path.  The bank is held as three int8 limbs of a 24-bit
- *              fixed-point encoding (per-template power-of-two scale) and
- *              accumulated exactly in int32; the only error is the weight
- *              quantisation (<= 2^-24 * max|W_m| per tap), far inside the 1e-4
- *              relative parity bar and independent of summation order.
- *   TSR_TRUNCATE: windows overhanging the end of an utterance keep their
- *              partial sum instead of the reference's 0 (the
- *              get_max_detect_examples convention, :58-59).  OR-able. */
-enum { TSR_EXACT = 0, TSR_FAST = 1, TSR_TRUNCATE = 16 };
+ *   TSR_FAST : MFMA path.  The bank is held as int8 limbs of a fixed-point encoding
+ *              (per-template scale) and accumulated exactly in integers, so results
+ *              are independent of summation order and bit-reproducible; the only
+ *              error is the weight quantisation.  Two limbs (16-bit weights):
+ *              <= 2^-16 * max|W_m| per tap -- the size of the rounding noise of the
+ *              reference's own f32 sum, ~1e-6 relative on a window score.
+ *   TSR_FAST | TSR_W24: three limbs (23-bit weights, power-of-two scale),
+ *              <= 2^-22 * max|W_m| per tap, at 1.5x the matrix-core work. */
+enum { TSR_EXACT = 0, TSR_FAST = 1, TSR_W24 = 2 };
 
 typedef struct tsr_ctx tsr_ctx;       /* device + stream + scratch                 */
 typedef struct tsr_bank tsr_bank;     /* device-resident template bank             */

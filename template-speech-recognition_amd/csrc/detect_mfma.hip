@@ -12,14 +12,17 @@
 // No im2col, no padding of the bank to a common length, every frame is read once.
 //
 // Arithmetic -- exact integers.  X is {0,1} bytes, i.e. already an int8 operand.
-// Each template's f32 weights are quantised ONCE (bank build) to a 23-bit signed
-// fixed point with a per-template power-of-two scale and split into three signed
-// int8 limbs q = l2*65536 + l1*256 + l0.  Three v_mfma_i32_32x32x32_i8 per
-// K-block accumulate the limbs in int32; sums are exact, so the result does not
-// depend on tiling, wave count or summation order (bit-reproducible), and the only
-// deviation from the f32 reference is the weight quantisation (<= 2^-22 max|W_m|
-// per tap).  int8 MFMA runs at 2x the bf16 rate, so three limbs cost 1.5 bf16
-// passes -- cheaper than the two f16/bf16 limbs an equally safe float split needs.
+// Each template's f32 weights are quantised ONCE (bank build) to a signed fixed point
+// with a per-template scale and split into NL signed int8 limbs (balanced base 256):
+//   TSR_FAST            NL = 2, 16-bit weights (|q| <= 127*256): per-tap error
+//                       <= 2^-16 max|W_m|, i.e. the same order as the rounding noise of
+//                       the reference's own sequential f32 sum; int32 ring;
+//   TSR_FAST | TSR_W24  NL = 3, 23-bit weights, power-of-two scale: per-tap error
+//                       <= 2^-22 max|W_m|; int64 ring.
+// NL v_mfma_i32_32x32x32_i8 per K-block accumulate the limbs in int32; all sums are exact,
+// so the result does not depend on tiling, wave count or summation order (bit-reproducible)
+// and the only deviation from the f32 reference is the weight quantisation.  int8 MFMA runs
+// at 2x the bf16 rate: two limbs cost one bf16 pass and are ~100x more accurate than bf16.
 //
 // Data movement.
 //   * Weights are REGISTER-STATIONARY: a workgroup is 8 waves = CT column tiles
@@ -59,13 +62,11 @@ constexpr int kThreads = kWaves * 64;
 constexpr int kMaxNKB = 12;   // K-blocks (of 32 features) a wave keeps in registers
 constexpr int kMaxSlots = 64; // template fragments per workgroup (ring rows)
 
-struct SlotMeta {  // one template fragment handled by a workgroup (LDS copy, 32 bytes)
-    double inv_scale;  // 2^-e_m
-    float cf;          // f32(c_m)
-    int L;             // template length
-    int tmpl;          // template id
-    int frag;          // row of raw_frag this slot writes (G > 1)
-    int pad[2];
+struct SlotMeta {  // one template fragment handled by a workgroup (LDS copy, 16 bytes)
+    float inv_scale;  // 2^-e_m (exact power of two)
+    float cf;         // f32(c_m)
+    int L;            // template length
+    int tf;           // template id (G == 1) or row of raw_frag (G > 1)
 };
 
 struct FastArgs {
@@ -85,6 +86,7 @@ struct FastArgs {
     int64_t P;
     int ring;                // ring length in frames (power of two)
     int lag;                 // tiles between emitting a tile and finishing it
+    int lmax1;               // Lmax - 1
     float *scores;           // fused outputs (G == 1)
     int32_t *ids;
     float *all;              // [M][P] per-template scores (G == 1, optional)
@@ -123,9 +125,15 @@ __device__ __forceinline__ void lds_dma4(const void *gsrc, unsigned lds_dst_wave
 }
 __device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int NKB>
+template <int NL> struct RingT { using type = long long; };
+template <> struct RingT<2> { using type = int; };
+
+// NKB: K-blocks (of 32 features) per wave; NL: int8 limbs per weight (2: 16-bit fixed point,
+// int32 ring; 3: 23-bit fixed point, int64 ring); FLAT: LDS row stride == resident row stride.
+template <int NKB, int NL, bool FLAT>
 __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a)
 {
+    using ring_t = typename RingT<NL>::type;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -137,52 +145,61 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
     const int nT = (r1 - o0 + 31) >> 5;
     const int nslots = a.g_nslots[cg];
 
-    // ---- LDS carve-up: [tile 0][tile 1][slot meta][utt_end ring][ring: (nslots+1) x int64] ---
-    uint8_t *xbuf0 = smem;
-    uint8_t *xbuf1 = smem + a.tile_bytes;
-    SlotMeta *meta = reinterpret_cast<SlotMeta *>(smem + 2 * a.tile_bytes);
-    int *uend_ring = reinterpret_cast<int *>(meta + kMaxSlots);  // utt_end of the frames in flight
-    long long *ring = reinterpret_cast<long long *>(uend_ring + a.ring + 64);
-    const int dummy = nslots * a.ring;  // out-of-range emissions land here, never read
-    for (int i = tid; i < (nslots + 1) * a.ring; i += kThreads) ring[i] = 0;
+    // ---- LDS carve-up: [tile 0][tile 1][tile 2][slot meta][result staging][utt_end ring]
+    //      [ring: (nslots+1) rows] -----------------------------------------------------------
+    // A ring row holds one partial-sum cell per frame in flight (a.ring of them, power of
+    // two) PLUS 32 overflow cells: a tile's 32 rows are emitted at cell (first & mask) + 0..31
+    // without wrapping, so the 16 atomics of a lane share one address register and differ
+    // only in their immediate offset; the finishing pass folds overflow cell i into cell i.
+    auto xbuf = [&](int t) { return smem + (t % 3) * a.tile_bytes; };
+    SlotMeta *meta = reinterpret_cast<SlotMeta *>(smem + 3 * a.tile_bytes);
+    int *out_stage = reinterpret_cast<int *>(meta + kMaxSlots);  // [tile parity][32 score bits | 32 ids]
+    int *uend_ring = out_stage + 128;                            // utt_end of the frames in flight
+    ring_t *ring = reinterpret_cast<ring_t *>(uend_ring + a.ring + 64);
+    const int ring_mask = a.ring - 1;
+    const int rstride = a.ring + 33;  // odd: a column of the ring hits distinct banks
+    const int dummy = nslots * rstride;  // out-of-range emissions land in this spare row
+    for (int i = tid; i < (nslots + 1) * rstride; i += kThreads) ring[i] = 0;
     if (tid < nslots) meta[tid] = a.slots[cg * kMaxSlots + tid];
 
     // ---- this wave's role and its register-stationary limb fragments --------------------
     const int ct = wave / a.KS, ks = wave - ct * a.KS;
     const int coltile = cg * a.CT + ct;
-    i32x4 b[NKB][3];
+    i32x4 b[NKB][NL];
     {
-        const i32x4 *wl = a.Wl + ((size_t)(coltile * a.KS + ks) * NKB * 3) * 64 + lane;
+        const i32x4 *wl = a.Wl + ((size_t)(coltile * a.KS + ks) * NKB * NL) * 64 + lane;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int l = 0; l < 3; ++l) b[kb][l] = wl[(kb * 3 + l) * 64];
+            for (int l = 0; l < NL; ++l) b[kb][l] = wl[(kb * NL + l) * 64];
     }
     const int col = coltile * 32 + (lane & 31);
     const int slot = a.col_slot[col];
     // padding columns get a tap index that pushes every target frame out of range
     const int tau = slot >= 0 ? a.col_tau[col] : (1 << 28);
-    const int rbase = (slot >= 0 ? slot : 0) * a.ring;
     const int half = lane >> 5;
-    const int ring_mask = a.ring - 1;
+    ring_t *const my_row = ring + (slot >= 0 ? slot : nslots) * rstride;
+    ring_t *const dummy_row = ring + dummy;
+    const int kl = 4 * half - tau;  // frame (relative to the tile's first row) of accumulator row 0
 
-    // ---- frame tiles: tile t = rows [o0 + 32 t, +32), copied flat by LDS-DMA -------------
+    // ---- frame tiles: tile t = rows [o0 + 32 t, +32), copied by LDS-DMA --------------------
     // one DMA instruction moves 1 KiB (64 lanes x 16 B); wave w issues pieces w, w+8, ...
     const int n_pieces = a.tile_bytes >> 10;
     const int slots_per_row = a.SB >> 4, src_slots = a.Dp >> 4;
     auto stage = [&](int t, uint8_t *dst) {
         if (TSR_ABL & 8) return;
         const uint8_t *src_tile = a.X + ((int64_t)o0 + 32 * (int64_t)t) * a.Dp;
+        const unsigned dst0 = lds_addr(dst);
         for (int pc = wave; pc < n_pieces; pc += kWaves) {
             const int chunk = pc * 64 + lane;  // 16-byte slot of the LDS tile
             const uint8_t *src;
-            if (slots_per_row == src_slots) {
-                src = src_tile + (int64_t)chunk * 16;
+            if (FLAT) {
+                src = src_tile + chunk * 16;
             } else {  // LDS rows carry one extra (unused) slot to keep the stride odd
                 const int row = chunk / slots_per_row, c16 = chunk - row * slots_per_row;
                 src = src_tile + (int64_t)row * a.Dp + min(c16, src_slots - 1) * 16;
             }
-            lds_dma16(src, __builtin_amdgcn_readfirstlane(lds_addr(dst) + pc * 1024));
+            lds_dma16(src, __builtin_amdgcn_readfirstlane(dst0 + pc * 1024));
         }
         // the utt_end values of the tile's 32 frames ride along (4-byte DMA, one wave): the
         // finishing pass must not issue register loads, or hipcc drains the tile DMA early
@@ -196,13 +213,12 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
 
     // Finishing pass for one of this lane's frames.  32 frames per tile are spread over the
     // whole workgroup: wave w takes frames 4w..4w+3, the 16 lanes of a frame (one DPP row)
-    // take slots lane%16 (+16, ...).  Split in three phases so that tile_step can issue them
-    // between MFMAs: (A) LDS reads + ring reset, (B) int64 -> f32 score, (C) max / first
-    // arg-max across the 16 lanes by DPP row rotations + the 8-byte result store.
+    // take slots lane%16 (+16, ...).  Three phases so that tile_step can issue them between
+    // MFMAs: (A) LDS reads + ring reset, (B) integer -> f32 score, (C) max / first arg-max
+    // across the 16 lanes by DPP row rotations, result parked in LDS for wave 0 to write out.
     const int fr_in_tile = 4 * wave + (lane >> 4);
     struct Fin {
-        long long q;
-        SlotMeta sm;
+        ring_t q;
         int uend, prel;
         float best;
         int besti;
@@ -211,49 +227,74 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
         fs.prel = f * 32 + fr_in_tile;
         const int ridx = fs.prel & ring_mask;
         fs.uend = uend_ring[ridx];
-        fs.sm = meta[min(s, kMaxSlots - 1)];
-        long long *cell = &ring[(s < nslots ? s : nslots) * a.ring + ridx];  // spare row when idle
+        ring_t *cell = ring + (s < nslots ? s : nslots) * rstride + ridx;  // spare row when idle
         fs.q = *cell;
         *cell = 0;
+        if (((32 * f) & ring_mask) == 0) {  // wave-uniform: this tile owns the overflow cells
+            fs.q += cell[a.ring];
+            cell[a.ring] = 0;
+        }
     };
     auto fin_b = [&](Fin &fs, int s) {
+        const SlotMeta sm = meta[min(s, kMaxSlots - 1)];
         const bool valid = fs.prel < nOut && s < nslots;
         const int64_t p = (int64_t)o0 + fs.prel;
-        const double x = (double)fs.q * fs.sm.inv_scale;
+        float x;
+        if (NL == 2) {
+            x = (float)fs.q * sm.inv_scale;  // |q| < 2^31: one rounding; the scale is a power of two
+        } else {
+            // exact int64 -> correctly rounded f32: q = hi*2^24 + lo, |hi| < 2^13, 0 <= lo < 2^24,
+            // both exact in f32, a single rounding in the fma
+            const long long q = fs.q;
+            x = __builtin_fmaf((float)(int)(q >> 24), 16777216.0f, (float)((unsigned)q & 0xffffffu)) *
+                sm.inv_scale;
+        }
         if (a.raw_frag) {  // several column groups: partial sums, finished by the epilogue kernel
-            if (valid) a.raw_frag[(int64_t)fs.sm.frag * a.P + p] = (float)x;
+            if (valid) a.raw_frag[(int64_t)sm.tf * a.P + p] = x;
             return;
         }
         // tail t > T - L_m scores 0 (+ c_m), as the reference's zero tail does
-        const float raw = (p + fs.sm.L <= fs.uend) ? (float)x : 0.0f;
-        const float sc = raw + fs.sm.cf;
-        if (a.all && valid) a.all[(int64_t)fs.sm.tmpl * a.P + p] = sc;
-        if (s < nslots && (sc > fs.best || (sc == fs.best && fs.sm.tmpl < fs.besti))) {
+        const float raw = (p + sm.L <= fs.uend) ? x : 0.0f;
+        const float sc = raw + sm.cf;
+        if (a.all && valid) a.all[(int64_t)sm.tf * a.P + p] = sc;
+        if (s < nslots && (sc > fs.best || (sc == fs.best && sm.tf < fs.besti))) {
             fs.best = sc;  // first maximum = lowest template id
-            fs.besti = fs.sm.tmpl;
+            fs.besti = sm.tf;
         }
     };
-    auto fin_c = [&](Fin &fs) {
+    auto fin_c = [&](Fin &fs, int f) {
         if (a.raw_frag || !a.scores) return;
-#define TSR_DPP_STEP(ctrl)                                                                        \
-    {                                                                                             \
-        const float ob = __builtin_bit_cast(                                                      \
-            float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, fs.best), ctrl, 0xf, 0xf, false)); \
-        const int oi = __builtin_amdgcn_update_dpp(0, fs.besti, ctrl, 0xf, 0xf, false);           \
-        if (ob > fs.best || (ob == fs.best && oi < fs.besti)) {                                   \
-            fs.best = ob;                                                                         \
-            fs.besti = oi;                                                                        \
-        }                                                                                         \
-    }
-        TSR_DPP_STEP(0x128)  // row_ror:8
-        TSR_DPP_STEP(0x124)  // row_ror:4
-        TSR_DPP_STEP(0x122)  // row_ror:2
-        TSR_DPP_STEP(0x121)  // row_ror:1
-#undef TSR_DPP_STEP
-        if ((lane & 15) == 0 && fs.prel < nOut) {
-            const int64_t p = (int64_t)o0 + fs.prel;
-            a.scores[p] = fs.best;
-            a.ids[p] = fs.besti;
+        // row (16-lane) all-reduce by DPP rotations: the maximum, then the lowest template id
+        // among the lanes that hold it (strict '>' in the reference = first maximum wins)
+#define TSR_ROR(x, n) __builtin_amdgcn_update_dpp(0, (x), 0x120 + (n), 0xf, 0xf, false)
+        float bm = fs.best;
+        bm = fmaxf(bm, __builtin_bit_cast(float, TSR_ROR(__builtin_bit_cast(int, bm), 8)));
+        bm = fmaxf(bm, __builtin_bit_cast(float, TSR_ROR(__builtin_bit_cast(int, bm), 4)));
+        bm = fmaxf(bm, __builtin_bit_cast(float, TSR_ROR(__builtin_bit_cast(int, bm), 2)));
+        bm = fmaxf(bm, __builtin_bit_cast(float, TSR_ROR(__builtin_bit_cast(int, bm), 1)));
+        int bi = (fs.best == bm) ? fs.besti : 0x7fffffff;
+        bi = min(bi, TSR_ROR(bi, 8));
+        bi = min(bi, TSR_ROR(bi, 4));
+        bi = min(bi, TSR_ROR(bi, 2));
+        bi = min(bi, TSR_ROR(bi, 1));
+#undef TSR_ROR
+        if ((lane & 15) == 0) {  // staged in LDS; wave 0 writes the tile's 32 results coalesced
+            out_stage[(f & 1) * 64 + fr_in_tile] = __builtin_bit_cast(int, bm);
+            out_stage[(f & 1) * 64 + 32 + fr_in_tile] = bi;
+        }
+    };
+    // results of finished tile f: LDS staging -> scores[32 f ..], ids[32 f ..] (wave 0 only,
+    // after the barrier that follows the tile's fin_c)
+    auto flush_tile = [&](int f) {
+        if (a.raw_frag || !a.scores || wave != 0) return;
+        const int prel = f * 32 + (lane & 31);
+        const int val = out_stage[(f & 1) * 64 + lane];
+        if (prel < nOut) {
+            const int64_t p = (int64_t)o0 + prel;
+            if (lane < 32)
+                a.scores[p] = __builtin_bit_cast(float, val);
+            else
+                a.ids[p] = val;
         }
     };
     auto finish_tile = [&](int f) {  // stand-alone form (pipeline drain, > 16 slots)
@@ -265,99 +306,147 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
             fin_a(fs, f, s);
             fin_b(fs, s);
         }
-        fin_c(fs);
+        fin_c(fs, f);
+    };
+    // s_waitcnt vmcnt(n) needs an immediate: leave this wave's `n` youngest DMA pieces (the
+    // tile after next) in flight, everything older -- the next tile -- has landed
+    auto dma_wait_all_but = [&](int n) {
+        switch (n) {
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
     };
 
-    // One tile step: 32 frames x 32 columns x (NKB*32) features in three limbs (36 MFMAs at
-    // NKB = 12) -> one exact int32 per element in vn (|sum| <= NKB*32 * 2^22 < 2^31, weights
-    // are quantised to |q| <= 2^22), WHILE the previous tile's sums `v` go through the skew
-    // reduction -- G[row, (m, tau)] adds into frame row - tau of its template (ring, LDS
-    // atomics) -- and an older tile `fin` is finished.  Emission and finishing are spread
-    // over the K-block steps so that their VALU and LDS work issues in the shadow of the
-    // MFMAs; sched_barrier keeps hipcc from clustering them behind the last MFMA.
-    // Accumulator register r of lane (col, half) is row (r&3) + 8 (r>>2) + 4 half.  No
-    // branches: out-of-range targets go to the spare ring row.
+    // One tile step: 32 frames x 32 columns x (NKB*32) features in NL limbs (NL*NKB MFMAs)
+    // -> one exact int32 per element in vn (|sum| <= NKB*32 * 2^(8 NL - 2) < 2^31), WHILE the
+    // previous tile's sums `v` go through the skew reduction -- G[row, (m, tau)] adds into
+    // frame row - tau of its template (ring, LDS atomics) -- and an older tile `fin` is
+    // finished.  Emission and finishing are spread over the K-block steps so that their VALU
+    // and LDS work issues in the shadow of the MFMAs; sched_barrier keeps hipcc from
+    // clustering them behind the last MFMA.  Accumulator register r of lane (col, half) is
+    // row (r&3) + 8 (r>>2) + 4 half.  Interior tiles (every target frame inside the segment)
+    // take no range check; otherwise out-of-range targets go to the spare ring row.
     auto tile_step = [&](const uint8_t *xt, i32x16 &vn, bool do_mfma, int te, const i32x16 &v,
-                         bool do_emit, int fin, bool do_fin) {
-        i32x16 acc0 = {}, acc1 = {}, acc2 = {};
+                         bool do_emit, bool interior, int fin, bool do_fin) {
+        i32x16 acc[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) acc[l] = (i32x16){};
         const uint8_t *xa = xt + a_off;
-        const int pbase = te * 32 + 4 * half - tau;
+        const int first = kl + 32 * te;          // target frame of accumulator row 0
+        ring_t *const cell0 = my_row + (first & ring_mask);
+        ring_t *const dcell0 = dummy_row + (first & ring_mask);
         Fin fs;
         fs.best = -INFINITY;
         fs.besti = 0x7fffffff;
         constexpr int kA = 0, kB = (NKB * 2) / 5, kC = (NKB * 3) / 5;  // steps of the finish phases
         i32x4 av = *reinterpret_cast<const i32x4 *>(xa);
-        i32x4 av1 = av;
-        if (NKB > 1) av1 = *reinterpret_cast<const i32x4 *>(xa + 32);
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            i32x4 av2 = av1;  // A fragments are fetched two K-blocks ahead of their MFMAs
-            if (kb + 2 < NKB) av2 = *reinterpret_cast<const i32x4 *>(xa + (kb + 2) * 32);
+            i32x4 av1 = av;  // the A fragment of the next K-block is fetched ahead of its MFMAs
+            if (kb + 1 < NKB) av1 = *reinterpret_cast<const i32x4 *>(xa + (kb + 1) * 32);
             if (do_mfma) {
                 if (TSR_ABL & 2) {
-                    asm volatile("" ::"v"(av), "v"(b[kb][0]), "v"(b[kb][1]), "v"(b[kb][2]));
+                    asm volatile("" ::"v"(av), "v"(b[kb][0]), "v"(b[kb][NL - 1]));
                 } else {
-                    acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b[kb][0], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b[kb][1], acc1, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b[kb][2], acc2, 0, 0, 0);
+#pragma unroll
+                    for (int l = 0; l < NL; ++l)
+                        acc[l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b[kb][l], acc[l], 0, 0, 0);
                 }
             }
             if (do_emit && !(TSR_ABL & 1)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     if (r * NKB / 16 != kb) continue;  // compile-time after unrolling
-                    const int prel = pbase + (r & 3) + 8 * (r >> 2);
-                    const int idx = (((unsigned)prel < (unsigned)nOut) ? rbase : dummy) + (prel & ring_mask);
-                    atomicAdd(reinterpret_cast<unsigned long long *>(&ring[idx]),
-                              (unsigned long long)(long long)v[r]);
+                    constexpr int dummy_c = 0;
+                    (void)dummy_c;
+                    const int c = (r & 3) + 8 * (r >> 2);
+                    ring_t *cell = cell0 + c;
+                    if (!interior) cell = ((unsigned)(first + c) < (unsigned)nOut) ? cell : dcell0 + c;
+                    if (NL == 2)
+                        atomicAdd(reinterpret_cast<unsigned int *>(cell), (unsigned int)v[r]);
+                    else
+                        atomicAdd(reinterpret_cast<unsigned long long *>(cell),
+                                  (unsigned long long)(long long)v[r]);
                 }
             }
             if (do_fin && !(TSR_ABL & 4)) {
                 if (kb == kA) fin_a(fs, fin, lane & 15);
                 if (kb == kB) fin_b(fs, lane & 15);
-                if (kb == kC) fin_c(fs);
+                if (kb == kC) fin_c(fs, fin);
             }
             __builtin_amdgcn_sched_barrier(0);
             av = av1;
-            av1 = av2;
         }
-        if (TSR_ABL & 3) asm volatile("" : "+v"(acc0), "+v"(acc1), "+v"(acc2));
+        if (TSR_ABL & 3) {
+#pragma unroll
+            for (int l = 0; l < NL; ++l) asm volatile("" : "+v"(acc[l]));
+        }
         if (do_mfma) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) vn[r] = (acc2[r] * 256 + acc1[r]) * 256 + acc0[r];
+            for (int r = 0; r < 16; ++r) {
+                int x = acc[NL - 1][r];
+#pragma unroll
+                for (int l = NL - 2; l >= 0; --l) x = x * 256 + acc[l][r];
+                vn[r] = x;
+            }
         }
     };
 
-    // ---- software pipeline: MFMA(t) runs beside the emission of tile t-1 and the finishing
-    //      of tile t - lag (one barrier per tile) ------------------------------------------
+    // ---- software pipeline, one barrier per tile.  Iteration t: the DMA of tile t+2 is
+    //      issued, the MFMAs of tile t run beside the skew emission of tile t-1 and the
+    //      finishing of tile t-lag, wave 0 writes out the tile finished one iteration ago.
     // finish(f) needs every tile up to f + a.lag emitted; emission(t-1) is only complete at
     // the barrier that ends iteration t, so iteration t may finish f = t - a.lag - 2.
     const int lag = a.lag + 2;
     const bool inl = nslots <= 16;  // finishing pass rides inside tile_step
+    // a wave whose 32 columns are all real taps can skip the range check on tiles whose
+    // targets [32 te - (Lmax-1), 32 te + 31 + 4] all lie inside the segment's outputs
+    const bool no_pad = __all(slot >= 0);
+    const int lmax1 = a.lmax1;
+    // DMA instructions this wave issues per tile (pieces wave, wave+8, ... and the utt_end row)
+    const int my_dma = (wave < n_pieces ? (n_pieces - wave + kWaves - 1) / kWaves : 0) +
+                       (wave == kWaves - 1 ? 1 : 0);
     i32x16 v = {};
-    if (nT > 0) stage(0, xbuf0);
-    dma_drain();
+    if (nT > 0) stage(0, xbuf(0));
+    if (nT > 1) stage(1, xbuf(1));
+    dma_wait_all_but(nT > 1 ? my_dma : 0);
     __syncthreads();  // ring/meta initialised, tile 0 landed
     if (nT > 0) {
-        if (nT > 1) stage(1, xbuf1);
-        tile_step(xbuf0, v, true, 0, v, false, 0, false);
-        dma_drain();
-        __syncthreads();
+        if (nT > 2) stage(2, xbuf(2));
+        tile_step(xbuf(0), v, true, 0, v, false, false, 0, false);
+        dma_wait_all_but(nT > 2 ? my_dma : 0);
+        __syncthreads();  // tile 1 landed
     }
+    int f_done = -1;  // tile whose results sit in the LDS staging row
     for (int t = 1; t < nT; ++t) {
-        if (t + 1 < nT) stage(t + 1, (t & 1) ? xbuf0 : xbuf1);
+        if (f_done >= 0) flush_tile(f_done);  // stores go ahead of this iteration's DMA
+        if (t + 2 < nT) stage(t + 2, xbuf(t + 2));
         i32x16 vn;
         const int f = t - lag;
-        tile_step((t & 1) ? xbuf1 : xbuf0, vn, true, t - 1, v, true, f, inl && f >= 0);
+        const bool interior = no_pad && 32 * (t - 1) >= lmax1 && 32 * (t - 1) + 35 < nOut;
+        if (interior)
+            tile_step(xbuf(t), vn, true, t - 1, v, true, true, f, inl && f >= 0);
+        else
+            tile_step(xbuf(t), vn, true, t - 1, v, true, false, f, inl && f >= 0);
         v = vn;
         if (!inl && f >= 0) finish_tile(f);
-        dma_drain();
-        __syncthreads();  // tile t-1 fully emitted; tile t+1 landed
+        f_done = f;
+        dma_wait_all_but(t + 2 < nT ? my_dma : 0);
+        __syncthreads();  // tile t-1 fully emitted; tile t+1 landed; tile f's results staged
     }
-    if (nT > 0) tile_step(xbuf0, v, false, nT - 1, v, true, 0, false);
+    if (f_done >= 0) flush_tile(f_done);
+    if (nT > 0) tile_step(xbuf(0), v, false, nT - 1, v, true, false, 0, false);
     __syncthreads();
     const int nF = (nOut + 31) >> 5;
-    for (int f = max(nT - lag, 0); f < nF; ++f) finish_tile(f);
+    for (int f = max(nT - lag, 0); f < nF; ++f) {
+        finish_tile(f);
+        __syncthreads();
+        flush_tile(f);
+        __syncthreads();
+    }
 }
 
 // (G > 1) sum the fragments of every template, then the reference epilogue.
@@ -388,6 +477,7 @@ __global__ __launch_bounds__(256) void frag_epilogue_kernel(
 }
 
 struct FastBank {
+    int NL = 0;  // int8 limbs per weight
     int NKB = 0, KS = 0, CT = 0, G = 0, nkb_total = 0, n_coltiles = 0, n_frag = 0;
     i32x4 *d_Wl = nullptr;
     int32_t *d_col_slot = nullptr, *d_col_tau = nullptr, *d_g_nslots = nullptr;
@@ -405,21 +495,29 @@ int upload(tsr_ctx *ctx, T **dptr, const std::vector<T> &v)
     return TSR_OK;
 }
 
-template <int NKB>
-int launch(tsr_ctx *ctx, const FastArgs &args, int grid, size_t lds)
+template <int NKB, int NL, bool FLAT>
+int launch3(tsr_ctx *ctx, const FastArgs &args, int grid, size_t lds)
 {
-    TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fast_bank_kernel<NKB>),
+    TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fast_bank_kernel<NKB, NL, FLAT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(fast_bank_kernel<NKB>, dim3(grid), dim3(kThreads), lds, ctx->stream, args);
+    hipLaunchKernelGGL((fast_bank_kernel<NKB, NL, FLAT>), dim3(grid), dim3(kThreads), lds, ctx->stream,
+                       args);
     TSR_HIP(hipGetLastError());
     return TSR_OK;
 }
 
+template <int NKB>
+int launch(tsr_ctx *ctx, const FastArgs &args, int grid, size_t lds, int NL, bool flat)
+{
+    if (NL == 2) return flat ? launch3<NKB, 2, true>(ctx, args, grid, lds) : launch3<NKB, 2, false>(ctx, args, grid, lds);
+    return flat ? launch3<NKB, 3, true>(ctx, args, grid, lds) : launch3<NKB, 3, false>(ctx, args, grid, lds);
+}
+
 }  // namespace
 
-void tsr_fast_bank_free(tsr_bank *bank)
+static void fast_bank_free_one(tsr_bank *bank, int which)
 {
-    FastBank *fb = static_cast<FastBank *>(bank->fast);
+    FastBank *fb = static_cast<FastBank *>(bank->fast[which]);
     if (!fb) return;
     (void)hipSetDevice(bank->device);
     (void)hipDeviceSynchronize();
@@ -430,10 +528,18 @@ void tsr_fast_bank_free(tsr_bank *bank)
     (void)hipFree(fb->d_frag_first);
     (void)hipFree(fb->d_slots);
     delete fb;
-    bank->fast = nullptr;
+    bank->fast[which] = nullptr;
 }
 
-int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank)
+void tsr_fast_bank_free(tsr_bank *bank)
+{
+    fast_bank_free_one(bank, 0);
+    fast_bank_free_one(bank, 1);
+}
+
+// NL = 2: 16-bit fixed point (two int8 limbs, int32 ring); NL = 3: 23-bit (three limbs,
+// int64 ring).  Built lazily, cached in bank->fast[NL - 2].
+int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int NL)
 {
     const int M = bank->M;
     const int64_t D = bank->D;
@@ -450,9 +556,12 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank)
     const int n_coltiles = (int)((C + 31) / 32);
     const int G = (n_coltiles + CT - 1) / CT;
 
-    // ---- per-template power-of-two scale and the three int8 limbs --------------------------
+    // ---- per-template scale and the int8 limbs ------------------------------------------------
+    // NL = 3: q = rint(W * 2^e) with |q| <= 2^22 (power-of-two scale, exactly invertible).
+    // NL = 2: q = rint(W * qmax / max|W|), qmax = min(127*256, (2^31-1) / (L_m * D)) so that the
+    //         int32 ring cannot overflow even if every feature of every tap is set.
     std::vector<double> inv_scale(M);
-    std::vector<int8_t> limbs((size_t)3 * C * D);  // [limb][column][d]
+    std::vector<int8_t> limbs((size_t)NL * C * D);  // [limb][column][d]
     std::vector<int32_t> col_tmpl((size_t)C), col_tau_v((size_t)C);
     {
         int64_t woff = 0, c0 = 0;
@@ -461,27 +570,33 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank)
             const float *w = bank->W_cat.data() + woff;
             float mx = 0.0f;
             for (int64_t i = 0; i < n; ++i) mx = std::max(mx, fabsf(w[i]));
-            int e = 0;
+            double sc = 1.0;
             if (mx > 0.0f) {
-                int ex;
-                frexpf(mx, &ex);  // mx = f * 2^ex, f in [0.5, 1)  =>  mx * 2^(22-ex) in [2^21, 2^22)
-                e = 22 - ex;
+                if (NL == 3) {
+                    int ex;
+                    frexpf(mx, &ex);  // mx = f * 2^ex, f in [0.5, 1)  =>  mx * 2^(22-ex) in [2^21, 2^22)
+                    sc = ldexp(1.0, std::min(22 - ex, 120));  // keep 2^-e a normal f32
+                } else {
+                    const double qmax = std::min<double>(127.0 * 256.0, floor(2147483647.0 / (double)n));
+                    if (qmax < 1.0) {
+                        tsr_set_error("TSR_FAST: template %d has %lld taps; too many for the int32 ring", m, (long long)n);
+                        return TSR_ERR_UNSUPPORTED;
+                    }
+                    sc = qmax / (double)mx;
+                }
             }
-            const double s = ldexp(1.0, e);
-            inv_scale[m] = ldexp(1.0, -e);
+            inv_scale[m] = 1.0 / sc;
             for (int tau = 0; tau < bank->L[m]; ++tau) {
                 const int64_t c = c0 + tau;
                 col_tmpl[(size_t)c] = m;
                 col_tau_v[(size_t)c] = tau;
                 for (int64_t d = 0; d < D; ++d) {
-                    const int q = (int)llrint((double)w[tau * D + d] * s);  // |q| <= 2^22
-                    const int l0 = ((q + 128) & 255) - 128;
-                    const int q1 = (q - l0) >> 8;
-                    const int l1 = ((q1 + 128) & 255) - 128;
-                    const int l2 = (q1 - l1) >> 8;  // |l2| <= 65
-                    limbs[((size_t)0 * C + c) * D + d] = (int8_t)l0;
-                    limbs[((size_t)1 * C + c) * D + d] = (int8_t)l1;
-                    limbs[((size_t)2 * C + c) * D + d] = (int8_t)l2;
+                    int q = (int)llrint((double)w[tau * D + d] * sc);
+                    for (int l = 0; l < NL; ++l) {  // balanced base-256 digits, last one keeps the rest
+                        int digit = (l == NL - 1) ? q : ((q + 128) & 255) - 128;
+                        limbs[((size_t)l * C + c) * D + d] = (int8_t)digit;
+                        q = (q - digit) >> 8;
+                    }
                 }
             }
             woff += n;
@@ -494,6 +609,7 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank)
     std::vector<SlotMeta> slots((size_t)G * kMaxSlots);
     memset(slots.data(), 0, slots.size() * sizeof(SlotMeta));
     std::vector<int32_t> g_nslots(G, 0);
+    std::vector<int> slot_m, slot_f;  // template / fragment of every slot, in creation order
     int max_slots = 0;
     std::vector<std::vector<int>> frags_of(M);  // fragment ids per template, in column order
     int n_frag = 0;
@@ -507,11 +623,12 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank)
                     return TSR_ERR_UNSUPPORTED;
                 }
                 SlotMeta &sm = slots[(size_t)g * kMaxSlots + nslots];
-                sm.inv_scale = inv_scale[m];
+                sm.inv_scale = (float)inv_scale[m];
                 sm.cf = (float)bank->c[m];
                 sm.L = bank->L[m];
-                sm.tmpl = m;
-                sm.frag = n_frag;
+                sm.tf = -1;  // template id or fragment row, set once G is known to be 1 or more
+                slot_m.push_back(m);
+                slot_f.push_back(n_frag);
                 frags_of[m].push_back(n_frag);
                 ++n_frag;
                 ++nslots;
@@ -523,6 +640,12 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank)
         g_nslots[g] = nslots;
         max_slots = std::max(max_slots, nslots);
     }
+    {
+        size_t k = 0;
+        for (int g = 0; g < G; ++g)
+            for (int sidx = 0; sidx < g_nslots[g]; ++sidx, ++k)
+                slots[(size_t)g * kMaxSlots + sidx].tf = (G == 1) ? slot_m[k] : slot_f[k];
+    }
     // fragment ids are handed out in column order, so a template's fragments are consecutive
     std::vector<int32_t> frag_first(M + 1, 0);
     for (int m = 0; m < M; ++m) {
@@ -530,22 +653,23 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank)
         frag_first[m + 1] = frags_of[m].back() + 1;
     }
     // ---- limb fragments in register order: [coltile][ks][kb][limb][lane] x 16 bytes ------------
-    std::vector<i32x4> Wl((size_t)G * CT * KS * NKB * 3 * 64);
+    std::vector<i32x4> Wl((size_t)G * CT * KS * NKB * NL * 64);
     memset(Wl.data(), 0, Wl.size() * sizeof(i32x4));
     for (int64_t tile = 0; tile < (int64_t)G * CT; ++tile)
         for (int ks = 0; ks < KS; ++ks)
             for (int kb = 0; kb < NKB; ++kb)
-                for (int l = 0; l < 3; ++l)
+                for (int l = 0; l < NL; ++l)
                     for (int lane = 0; lane < 64; ++lane) {
                         const int64_t c = tile * 32 + (lane & 31);
                         if (c >= C) continue;
                         int8_t *dst = reinterpret_cast<int8_t *>(
-                            &Wl[((((size_t)tile * KS + ks) * NKB + kb) * 3 + l) * 64 + lane]);
+                            &Wl[((((size_t)tile * KS + ks) * NKB + kb) * NL + l) * 64 + lane]);
                         const int64_t k0 = ((int64_t)ks * NKB + kb) * 32 + 16 * (lane >> 5);
                         for (int e = 0; e < 16; ++e)
                             if (k0 + e < D) dst[e] = limbs[((size_t)l * C + c) * D + k0 + e];
                     }
     FastBank *fb = new FastBank;
+    fb->NL = NL;
     fb->NKB = NKB;
     fb->KS = KS;
     fb->CT = CT;
@@ -554,7 +678,7 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank)
     fb->n_coltiles = n_coltiles;
     fb->n_frag = n_frag;
     fb->max_slots = max_slots;
-    bank->fast = fb;
+    bank->fast[NL - 2] = fb;
     int s = upload(ctx, &fb->d_Wl, Wl);
     if (s == TSR_OK) s = upload(ctx, &fb->d_col_slot, col_slot);
     if (s == TSR_OK) s = upload(ctx, &fb->d_col_tau, col_tau);
@@ -562,7 +686,7 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank)
     if (s == TSR_OK) s = upload(ctx, &fb->d_frag_first, frag_first);
     if (s == TSR_OK) s = upload(ctx, &fb->d_slots, slots);
     if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
-    if (s != TSR_OK) tsr_fast_bank_free(bank);
+    if (s != TSR_OK) fast_bank_free_one(bank, NL - 2);
     return s;
 }
 
@@ -618,8 +742,8 @@ static int build_plan(tsr_ctx *ctx, tsr_corpus *cp, int nseg, int Lmax)
 int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int flags,
                          float *d_scores, int32_t *d_ids, float *d_all)
 {
-    (void)flags;
-    const FastBank *fb = static_cast<const FastBank *>(bank->fast);
+    const int NL = (flags & TSR_W24) ? 3 : 2;
+    const FastBank *fb = static_cast<const FastBank *>(bank->fast[NL - 2]);
     if (!fb) return TSR_ERR_UNSUPPORTED;
     const int64_t P = cp->P;
     if (P == 0) return TSR_OK;
@@ -637,8 +761,9 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
     int lag = (bank->Lmax - 1 + 31) / 32;
     int ring = 32;
     while (ring < 32 * (lag + 4)) ring *= 2;
-    const size_t lds = (size_t)2 * tile_bytes + (size_t)kMaxSlots * sizeof(SlotMeta) +
-                       (size_t)(ring + 64) * 4 + (size_t)(fb->max_slots + 1) * ring * 8;
+    const size_t lds = (size_t)3 * tile_bytes + (size_t)kMaxSlots * sizeof(SlotMeta) + 128 * 4 +
+                       (size_t)(ring + 64) * 4 +
+                       (size_t)(fb->max_slots + 1) * (ring + 33) * (NL == 2 ? 4 : 8) + 16;
     if (lds > 160 * 1024) {
         tsr_set_error("TSR_FAST: D=%lld, Lmax=%d need %zu bytes of LDS", (long long)bank->D, bank->Lmax, lds);
         return TSR_ERR_UNSUPPORTED;
@@ -669,6 +794,7 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
     a.P = P;
     a.ring = ring;
     a.lag = lag;
+    a.lmax1 = bank->Lmax - 1;
     void *raw_frag = nullptr;
     if (fb->G > 1) {
         TSR_TRY(tsr_scratch(ctx, 0, (size_t)fb->n_frag * P * sizeof(float), &raw_frag));
@@ -679,20 +805,21 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
         a.all = d_all;
     }
     const int grid = nseg * fb->G;
+    const bool flat = (SB == Dp);
     int s;
     switch (fb->NKB) {
-    case 1: s = launch<1>(ctx, a, grid, lds); break;
-    case 2: s = launch<2>(ctx, a, grid, lds); break;
-    case 3: s = launch<3>(ctx, a, grid, lds); break;
-    case 4: s = launch<4>(ctx, a, grid, lds); break;
-    case 5: s = launch<5>(ctx, a, grid, lds); break;
-    case 6: s = launch<6>(ctx, a, grid, lds); break;
-    case 7: s = launch<7>(ctx, a, grid, lds); break;
-    case 8: s = launch<8>(ctx, a, grid, lds); break;
-    case 9: s = launch<9>(ctx, a, grid, lds); break;
-    case 10: s = launch<10>(ctx, a, grid, lds); break;
-    case 11: s = launch<11>(ctx, a, grid, lds); break;
-    default: s = launch<12>(ctx, a, grid, lds); break;
+    case 1: s = launch<1>(ctx, a, grid, lds, NL, flat); break;
+    case 2: s = launch<2>(ctx, a, grid, lds, NL, flat); break;
+    case 3: s = launch<3>(ctx, a, grid, lds, NL, flat); break;
+    case 4: s = launch<4>(ctx, a, grid, lds, NL, flat); break;
+    case 5: s = launch<5>(ctx, a, grid, lds, NL, flat); break;
+    case 6: s = launch<6>(ctx, a, grid, lds, NL, flat); break;
+    case 7: s = launch<7>(ctx, a, grid, lds, NL, flat); break;
+    case 8: s = launch<8>(ctx, a, grid, lds, NL, flat); break;
+    case 9: s = launch<9>(ctx, a, grid, lds, NL, flat); break;
+    case 10: s = launch<10>(ctx, a, grid, lds, NL, flat); break;
+    case 11: s = launch<11>(ctx, a, grid, lds, NL, flat); break;
+    default: s = launch<12>(ctx, a, grid, lds, NL, flat); break;
     }
     TSR_TRY(s);
     if (fb->G > 1) {

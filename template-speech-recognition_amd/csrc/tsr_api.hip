@@ -381,12 +381,14 @@ static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp,
 {
     TSR_REQUIRE(ctx && bank && cp, "tsr_corpus_score: null pointer");
     TSR_REQUIRE(bank->D == cp->D, "tsr_corpus_score: bank D=%lld but corpus D=%lld", (long long)bank->D, (long long)cp->D);
-    TSR_REQUIRE((flags & ~(TSR_FAST)) == 0, "tsr_corpus_score: unknown flags 0x%x", flags);
+    TSR_REQUIRE((flags & ~(TSR_FAST | TSR_W24)) == 0, "tsr_corpus_score: unknown flags 0x%x", flags);
+    TSR_REQUIRE(!(flags & TSR_W24) || (flags & TSR_FAST), "tsr_corpus_score: TSR_W24 modifies TSR_FAST");
     if (cp->P == 0) return TSR_OK;
     TSR_HIP(hipSetDevice(ctx->device));
     if (flags & TSR_FAST) {
-        if (!bank->fast) {
-            int sb = tsr_fast_bank_build(ctx, const_cast<tsr_bank *>(bank));
+        const int NL = (flags & TSR_W24) ? 3 : 2;
+        if (!bank->fast[NL - 2]) {
+            int sb = tsr_fast_bank_build(ctx, const_cast<tsr_bank *>(bank), NL);
             if (sb != TSR_OK && sb != TSR_ERR_UNSUPPORTED) return sb;
         }
         int s = tsr_launch_fast_bank(ctx, bank, cp, flags, d_all ? nullptr : cp->d_scores,

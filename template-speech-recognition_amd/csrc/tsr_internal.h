@@ -87,8 +87,8 @@ struct tsr_bank {
     int32_t *d_gx_L = nullptr;
     int32_t *d_L = nullptr;          // [M]
     float *d_cf = nullptr;           // [M]  f32(c_m)
-    // device, fast path (built lazily by detect_mfma.hip)
-    void *fast = nullptr;
+    // device, fast path (built lazily by detect_mfma.hip): [0] two limbs, [1] three limbs
+    void *fast[2] = {nullptr, nullptr};
 };
 
 struct tsr_corpus {
@@ -131,7 +131,7 @@ int tsr_launch_max_detect_examples(tsr_ctx *ctx, const uint8_t *d_F, int64_t N, 
                                    int64_t D, const double *d_LF, int64_t L,
                                    const int64_t *d_lengths, double *d_tmp, double *d_out);
 // detect_mfma.hip
-int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank);
+int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int NL);
 void tsr_fast_bank_free(tsr_bank *bank);
 int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *corpus, int flags,
                          float *d_scores, int32_t *d_ids, float *d_all);
