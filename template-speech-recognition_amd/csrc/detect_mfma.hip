@@ -142,10 +142,10 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
     const int sg = blockIdx.x / a.G;   // frame-stream segment
     const int o0 = a.seg[sg], o1 = a.seg[a.nseg + sg], r1 = a.seg[2 * a.nseg + sg];
     const int nOut = o1 - o0;
-    const int nT = (r1 - o0 + 31) >> 5;
+    const int nT = (TSR_ABL & 16) ? 0 : (r1 - o0 + 31) >> 5;
     const int nslots = a.g_nslots[cg];
 
-    // ---- LDS carve-up: [tile 0][tile 1][tile 2][slot meta][result staging][utt_end ring]
+    // ---- LDS carve-up: [tile 0][tile 1][tile 2][slot meta][utt_end ring][max-key ring]
     //      [ring: (nslots+1) rows] -----------------------------------------------------------
     // A ring row holds one partial-sum cell per frame in flight (a.ring of them, power of
     // two) PLUS 32 overflow cells: a tile's 32 rows are emitted at cell (first & mask) + 0..31
@@ -153,9 +153,10 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
     // only in their immediate offset; the finishing pass folds overflow cell i into cell i.
     auto xbuf = [&](int t) { return smem + (t % 3) * a.tile_bytes; };
     SlotMeta *meta = reinterpret_cast<SlotMeta *>(smem + 3 * a.tile_bytes);
-    int *out_stage = reinterpret_cast<int *>(meta + kMaxSlots);  // [tile parity][32 score bits | 32 ids]
-    int *uend_ring = out_stage + 128;                            // utt_end of the frames in flight
-    ring_t *ring = reinterpret_cast<ring_t *>(uend_ring + a.ring + 64);
+    int *uend_ring = reinterpret_cast<int *>(meta + kMaxSlots);  // utt_end of the frames in flight
+    unsigned long long *maxring = reinterpret_cast<unsigned long long *>(uend_ring + a.ring + 64);
+    ring_t *ring = reinterpret_cast<ring_t *>(maxring + a.ring);
+    for (int i = tid; i < a.ring; i += kThreads) maxring[i] = 0;
     const int ring_mask = a.ring - 1;
     const int rstride = a.ring + 33;  // odd: a column of the ring hits distinct banks
     const int dummy = nslots * rstride;  // out-of-range emissions land in this spare row
@@ -211,42 +212,39 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
     // A-fragment address of this lane: row (lane & 31), K-group (lane >> 5) of its K-slice
     const int a_off = (lane & 31) * a.SB + half * 16 + ks * (NKB * 32);
 
-    // Finishing pass for one of this lane's frames.  32 frames per tile are spread over the
-    // whole workgroup: wave w takes frames 4w..4w+3, the 16 lanes of a frame (one DPP row)
-    // take slots lane%16 (+16, ...).  Three phases so that tile_step can issue them between
-    // MFMAs: (A) LDS reads + ring reset, (B) integer -> f32 score, (C) max / first arg-max
-    // across the 16 lanes by DPP row rotations, result parked in LDS for wave 0 to write out.
-    const int fr_in_tile = 4 * wave + (lane >> 4);
-    struct Fin {
-        ring_t q;
-        int uend, prel;
-        float best;
-        int besti;
-    };
-    auto fin_a = [&](Fin &fs, int f, int s) {
-        fs.prel = f * 32 + fr_in_tile;
-        const int ridx = fs.prel & ring_mask;
-        fs.uend = uend_ring[ridx];
-        ring_t *cell = ring + (s < nslots ? s : nslots) * rstride + ridx;  // spare row when idle
-        fs.q = *cell;
+    // ---- finishing pass -----------------------------------------------------------------------
+    // Phase AB (every wave, its own slots: s = wave + 16 j + 8 half; lane&31 is the frame):
+    // read and reset the ring cell (plus its overflow cell when this tile owns them),
+    // integer -> f32 score, zero tail, + c_m.  The max / first arg-max over templates is
+    // taken by the LDS: one ds_max_u64 per (frame, slot) of the key
+    //     (orderable(score) << 32) | ~template_id
+    // (larger score wins; on equal scores the lower id has the larger ~id, i.e. the
+    // reference's strict '>' = first maximum).
+    // Phase C (wave f % 8, one iteration later): decode the tile's 32 keys, lanes 0..31 store
+    // scores and lanes 32..63 ids -- two coalesced 128-byte stores.
+    auto fin_ab = [&](int f, int j) {
+        const int s = wave + 16 * j + 8 * half;
+        const int prel = f * 32 + (lane & 31);
+        const int ridx = prel & ring_mask;
+        ring_t *cell = ring + min(s, nslots) * rstride + ridx;  // spare row when s is past the end
+        ring_t q = *cell;
         *cell = 0;
         if (((32 * f) & ring_mask) == 0) {  // wave-uniform: this tile owns the overflow cells
-            fs.q += cell[a.ring];
+            q += cell[a.ring];
             cell[a.ring] = 0;
         }
-    };
-    auto fin_b = [&](Fin &fs, int s) {
         const SlotMeta sm = meta[min(s, kMaxSlots - 1)];
-        const bool valid = fs.prel < nOut && s < nslots;
-        const int64_t p = (int64_t)o0 + fs.prel;
+        const int uend = uend_ring[ridx];
+        const bool valid = prel < nOut && s < nslots;
+        const int64_t p = (int64_t)o0 + prel;
         float x;
         if (NL == 2) {
-            x = (float)fs.q * sm.inv_scale;  // |q| < 2^31: one rounding; the scale is a power of two
+            x = (float)q * sm.inv_scale;  // |q| < 2^31: one rounding
         } else {
             // exact int64 -> correctly rounded f32: q = hi*2^24 + lo, |hi| < 2^13, 0 <= lo < 2^24,
             // both exact in f32, a single rounding in the fma
-            const long long q = fs.q;
-            x = __builtin_fmaf((float)(int)(q >> 24), 16777216.0f, (float)((unsigned)q & 0xffffffu)) *
+            const long long qq = q;
+            x = __builtin_fmaf((float)(int)(qq >> 24), 16777216.0f, (float)((unsigned)qq & 0xffffffu)) *
                 sm.inv_scale;
         }
         if (a.raw_frag) {  // several column groups: partial sums, finished by the epilogue kernel
@@ -254,114 +252,92 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
             return;
         }
         // tail t > T - L_m scores 0 (+ c_m), as the reference's zero tail does
-        const float raw = (p + sm.L <= fs.uend) ? x : 0.0f;
+        const float raw = (p + sm.L <= uend) ? x : 0.0f;
         const float sc = raw + sm.cf;
         if (a.all && valid) a.all[(int64_t)sm.tf * a.P + p] = sc;
-        if (s < nslots && (sc > fs.best || (sc == fs.best && sm.tf < fs.besti))) {
-            fs.best = sc;  // first maximum = lowest template id
-            fs.besti = sm.tf;
+        if (a.scores && s < nslots) {
+            unsigned u = __builtin_bit_cast(unsigned, sc);
+            u ^= (unsigned)((int)u >> 31) | 0x80000000u;  // monotone map f32 -> u32
+            atomicMax(&maxring[ridx], ((unsigned long long)u << 32) | (unsigned)~sm.tf);
         }
     };
-    auto fin_c = [&](Fin &fs, int f) {
+    auto fin_c = [&](int f) {
         if (a.raw_frag || !a.scores) return;
-        // row (16-lane) all-reduce by DPP rotations: the maximum, then the lowest template id
-        // among the lanes that hold it (strict '>' in the reference = first maximum wins)
-#define TSR_ROR(x, n) __builtin_amdgcn_update_dpp(0, (x), 0x120 + (n), 0xf, 0xf, false)
-        float bm = fs.best;
-        bm = fmaxf(bm, __builtin_bit_cast(float, TSR_ROR(__builtin_bit_cast(int, bm), 8)));
-        bm = fmaxf(bm, __builtin_bit_cast(float, TSR_ROR(__builtin_bit_cast(int, bm), 4)));
-        bm = fmaxf(bm, __builtin_bit_cast(float, TSR_ROR(__builtin_bit_cast(int, bm), 2)));
-        bm = fmaxf(bm, __builtin_bit_cast(float, TSR_ROR(__builtin_bit_cast(int, bm), 1)));
-        int bi = (fs.best == bm) ? fs.besti : 0x7fffffff;
-        bi = min(bi, TSR_ROR(bi, 8));
-        bi = min(bi, TSR_ROR(bi, 4));
-        bi = min(bi, TSR_ROR(bi, 2));
-        bi = min(bi, TSR_ROR(bi, 1));
-#undef TSR_ROR
-        if ((lane & 15) == 0) {  // staged in LDS; wave 0 writes the tile's 32 results coalesced
-            out_stage[(f & 1) * 64 + fr_in_tile] = __builtin_bit_cast(int, bm);
-            out_stage[(f & 1) * 64 + 32 + fr_in_tile] = bi;
-        }
-    };
-    // results of finished tile f: LDS staging -> scores[32 f ..], ids[32 f ..] (wave 0 only,
-    // after the barrier that follows the tile's fin_c)
-    auto flush_tile = [&](int f) {
-        if (a.raw_frag || !a.scores || wave != 0) return;
         const int prel = f * 32 + (lane & 31);
-        const int val = out_stage[(f & 1) * 64 + lane];
+        const int ridx = prel & ring_mask;
+        const unsigned long long key = maxring[ridx];
+        __builtin_amdgcn_wave_barrier();  // both halves have read the cell before it is reset
+        if (half == 0) maxring[ridx] = 0;
         if (prel < nOut) {
             const int64_t p = (int64_t)o0 + prel;
-            if (lane < 32)
-                a.scores[p] = __builtin_bit_cast(float, val);
+            unsigned u = (unsigned)(key >> 32);
+            u ^= (~(unsigned)((int)u >> 31)) | 0x80000000u;  // inverse of the monotone map
+            if (half == 0)
+                a.scores[p] = __builtin_bit_cast(float, u);
             else
-                a.ids[p] = val;
+                a.ids[p] = (int)~(unsigned)key;
         }
     };
-    auto finish_tile = [&](int f) {  // stand-alone form (pipeline drain, > 16 slots)
-        if (TSR_ABL & 4) return;
-        Fin fs;
-        fs.best = -INFINITY;
-        fs.besti = 0x7fffffff;
-        for (int s = lane & 15; s < ((nslots + 15) & ~15); s += 16) {
-            fin_a(fs, f, s);
-            fin_b(fs, s);
-        }
-        fin_c(fs, f);
-    };
-    // s_waitcnt vmcnt(n) needs an immediate: leave this wave's `n` youngest DMA pieces (the
-    // tile after next) in flight, everything older -- the next tile -- has landed
-    auto dma_wait_all_but = [&](int n) {
-        switch (n) {
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        }
-    };
+    const int njs = (nslots - wave + 15) / 16;  // slot pairs this wave walks (wave-uniform)
 
-    // One tile step: 32 frames x 32 columns x (NKB*32) features in NL limbs (NL*NKB MFMAs)
-    // -> one exact int32 per element in vn (|sum| <= NKB*32 * 2^(8 NL - 2) < 2^31), WHILE the
-    // previous tile's sums `v` go through the skew reduction -- G[row, (m, tau)] adds into
-    // frame row - tau of its template (ring, LDS atomics) -- and an older tile `fin` is
-    // finished.  Emission and finishing are spread over the K-block steps so that their VALU
-    // and LDS work issues in the shadow of the MFMAs; sched_barrier keeps hipcc from
-    // clustering them behind the last MFMA.  Accumulator register r of lane (col, half) is
-    // row (r&3) + 8 (r>>2) + 4 half.  Interior tiles (every target frame inside the segment)
-    // take no range check; otherwise out-of-range targets go to the spare ring row.
-    auto tile_step = [&](const uint8_t *xt, i32x16 &vn, bool do_mfma, int te, const i32x16 &v,
-                         bool do_emit, bool interior, int fin, bool do_fin) {
+    // ---- the pipelined tile loop ----------------------------------------------------------
+    // Iteration t (one barrier, in the MIDDLE of the tile):
+    //   * MFMAs of tile t: NL*NKB v_mfma_i32_32x32x32_i8 -> one exact int32 per element
+    //     (|sum| <= NKB*32 * 2^(8 NL - 2) < 2^31).  A fragments come from a rolling queue that
+    //     is refilled PF K-blocks ahead and runs across the tile boundary, so the matrix
+    //     pipe never waits for LDS latency or for the barrier;
+    //   * skew emission of tile t-1: G[row, (m, tau)] adds into frame row - tau of its
+    //     template (ring, LDS atomics; accumulator register r of lane (col, half) is row
+    //     (r&3) + 8 (r>>2) + 4 half), spread over the K-block steps;
+    //   * mid-tile: drain the DMA of tile t+1, barrier, then the DMA of tile t+2 is issued
+    //     (its buffer was last read in iteration t-1, which every wave has left);
+    //   * second half: finishing phase AB of tile f = t - lag (every tile <= t-2 is fully
+    //     emitted once all waves passed the barrier) and phase C of tile f - 1.
+    // sched_barrier keeps hipcc from clustering the VALU/LDS work behind the last MFMA.
+    constexpr int H = NKB / 2;                            // K-block step that opens with the barrier
+    constexpr int PF = (NL == 2 ? 4 : 1) < (NKB - H) ? (NL == 2 ? 4 : 1) : (NKB - H);  // queue depth
+    constexpr int kAB = H + (NKB - H) / 3, kC = H + (2 * (NKB - H)) / 3;
+    const int lag = a.lag + 2;
+    // a wave whose 32 columns are all real taps can skip the range check on tiles whose
+    // targets [32 te - (Lmax-1), 32 te + 35] all lie inside the segment's outputs
+    const bool no_pad = __all(slot >= 0);
+    const int lmax1 = a.lmax1;
+    i32x4 aq[PF];
+    i32x16 v = {};
+
+    auto tile_iter = [&](int t, bool do_emit, bool interior, int fin) {
         i32x16 acc[NL];
 #pragma unroll
         for (int l = 0; l < NL; ++l) acc[l] = (i32x16){};
-        const uint8_t *xa = xt + a_off;
-        const int first = kl + 32 * te;          // target frame of accumulator row 0
+        const uint8_t *xa = xbuf(t) + a_off, *xn = xbuf(t + 1) + a_off;
+        const int first = kl + 32 * (t - 1);  // target frame of accumulator row 0 (tile t-1)
         ring_t *const cell0 = my_row + (first & ring_mask);
         ring_t *const dcell0 = dummy_row + (first & ring_mask);
-        Fin fs;
-        fs.best = -INFINITY;
-        fs.besti = 0x7fffffff;
-        constexpr int kA = 0, kB = (NKB * 2) / 5, kC = (NKB * 3) / 5;  // steps of the finish phases
-        i32x4 av = *reinterpret_cast<const i32x4 *>(xa);
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            i32x4 av1 = av;  // the A fragment of the next K-block is fetched ahead of its MFMAs
-            if (kb + 1 < NKB) av1 = *reinterpret_cast<const i32x4 *>(xa + (kb + 1) * 32);
-            if (do_mfma) {
-                if (TSR_ABL & 2) {
-                    asm volatile("" ::"v"(av), "v"(b[kb][0]), "v"(b[kb][NL - 1]));
-                } else {
+            if (kb == H) {
+                if (!(TSR_ABL & 128)) dma_drain();  // this wave's pieces of tile t+1 (and its stores) are done
+                if (!(TSR_ABL & 64)) __syncthreads();  // tile t+1 landed; tiles <= t-2 fully emitted
+                if (t + 2 < nT) stage(t + 2, xbuf(t + 2));
+            }
+            const i32x4 av = aq[0];
 #pragma unroll
-                    for (int l = 0; l < NL; ++l)
-                        acc[l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b[kb][l], acc[l], 0, 0, 0);
-                }
+            for (int i = 0; i + 1 < PF; ++i) aq[i] = aq[i + 1];
+            // refill: K-block kb+PF of this tile, or the head of the next tile (landed:
+            // kb+PF >= NKB only happens at steps >= H, behind the barrier)
+            const int nk = kb + PF;
+            aq[PF - 1] = *reinterpret_cast<const i32x4 *>(nk < NKB ? xa + nk * 32 : xn + (nk - NKB) * 32);
+            if (TSR_ABL & 2) {
+                asm volatile("" ::"v"(av), "v"(b[kb][0]), "v"(b[kb][NL - 1]));
+            } else {
+#pragma unroll
+                for (int l = 0; l < NL; ++l)
+                    acc[l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b[kb][l], acc[l], 0, 0, 0);
             }
             if (do_emit && !(TSR_ABL & 1)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     if (r * NKB / 16 != kb) continue;  // compile-time after unrolling
-                    constexpr int dummy_c = 0;
-                    (void)dummy_c;
                     const int c = (r & 3) + 8 * (r >> 2);
                     ring_t *cell = cell0 + c;
                     if (!interior) cell = ((unsigned)(first + c) < (unsigned)nOut) ? cell : dcell0 + c;
@@ -372,81 +348,65 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
                                   (unsigned long long)(long long)v[r]);
                 }
             }
-            if (do_fin && !(TSR_ABL & 4)) {
-                if (kb == kA) fin_a(fs, fin, lane & 15);
-                if (kb == kB) fin_b(fs, lane & 15);
-                if (kb == kC) fin_c(fs, fin);
+            if (!(TSR_ABL & 4)) {
+                if (kb == kAB && fin >= 0)
+                    for (int j = 0; j < njs; ++j) fin_ab(fin, j);
+                if (kb == kC && fin >= 1 && wave == ((fin - 1) & (kWaves - 1))) fin_c(fin - 1);
             }
             __builtin_amdgcn_sched_barrier(0);
-            av = av1;
         }
         if (TSR_ABL & 3) {
 #pragma unroll
             for (int l = 0; l < NL; ++l) asm volatile("" : "+v"(acc[l]));
         }
-        if (do_mfma) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int x = acc[NL - 1][r];
+        for (int r = 0; r < 16; ++r) {
+            int x = acc[NL - 1][r];
 #pragma unroll
-                for (int l = NL - 2; l >= 0; --l) x = x * 256 + acc[l][r];
-                vn[r] = x;
-            }
+            for (int l = NL - 2; l >= 0; --l) x = x * 256 + acc[l][r];
+            v[r] = x;
         }
     };
 
-    // ---- software pipeline, one barrier per tile.  Iteration t: the DMA of tile t+2 is
-    //      issued, the MFMAs of tile t run beside the skew emission of tile t-1 and the
-    //      finishing of tile t-lag, wave 0 writes out the tile finished one iteration ago.
-    // finish(f) needs every tile up to f + a.lag emitted; emission(t-1) is only complete at
-    // the barrier that ends iteration t, so iteration t may finish f = t - a.lag - 2.
-    const int lag = a.lag + 2;
-    const bool inl = nslots <= 16;  // finishing pass rides inside tile_step
-    // a wave whose 32 columns are all real taps can skip the range check on tiles whose
-    // targets [32 te - (Lmax-1), 32 te + 31 + 4] all lie inside the segment's outputs
-    const bool no_pad = __all(slot >= 0);
-    const int lmax1 = a.lmax1;
-    // DMA instructions this wave issues per tile (pieces wave, wave+8, ... and the utt_end row)
-    const int my_dma = (wave < n_pieces ? (n_pieces - wave + kWaves - 1) / kWaves : 0) +
-                       (wave == kWaves - 1 ? 1 : 0);
-    i32x16 v = {};
     if (nT > 0) stage(0, xbuf(0));
     if (nT > 1) stage(1, xbuf(1));
-    dma_wait_all_but(nT > 1 ? my_dma : 0);
-    __syncthreads();  // ring/meta initialised, tile 0 landed
+    dma_drain();
+    __syncthreads();  // ring/meta initialised, tiles 0 and 1 landed
     if (nT > 0) {
-        if (nT > 2) stage(2, xbuf(2));
-        tile_step(xbuf(0), v, true, 0, v, false, false, 0, false);
-        dma_wait_all_but(nT > 2 ? my_dma : 0);
-        __syncthreads();  // tile 1 landed
+#pragma unroll
+        for (int i = 0; i < PF; ++i) aq[i] = *reinterpret_cast<const i32x4 *>(xbuf(0) + a_off + i * 32);
     }
-    int f_done = -1;  // tile whose results sit in the LDS staging row
-    for (int t = 1; t < nT; ++t) {
-        if (f_done >= 0) flush_tile(f_done);  // stores go ahead of this iteration's DMA
-        if (t + 2 < nT) stage(t + 2, xbuf(t + 2));
-        i32x16 vn;
-        const int f = t - lag;
+    for (int t = 0; t < nT; ++t) {
         const bool interior = no_pad && 32 * (t - 1) >= lmax1 && 32 * (t - 1) + 35 < nOut;
         if (interior)
-            tile_step(xbuf(t), vn, true, t - 1, v, true, true, f, inl && f >= 0);
+            tile_iter(t, true, true, t - lag);
         else
-            tile_step(xbuf(t), vn, true, t - 1, v, true, false, f, inl && f >= 0);
-        v = vn;
-        if (!inl && f >= 0) finish_tile(f);
-        f_done = f;
-        dma_wait_all_but(t + 2 < nT ? my_dma : 0);
-        __syncthreads();  // tile t-1 fully emitted; tile t+1 landed; tile f's results staged
+            tile_iter(t, t > 0, false, t - lag);
     }
-    if (f_done >= 0) flush_tile(f_done);
-    if (nT > 0) tile_step(xbuf(0), v, false, nT - 1, v, true, false, 0, false);
+    // ---- drain: emit the last tile, then finish what is left ------------------------------------
+    if (nT > 0 && !(TSR_ABL & 1)) {
+        const int first = kl + 32 * (nT - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2);
+            ring_t *cell = (((unsigned)(first + c) < (unsigned)nOut) ? my_row : dummy_row) + (first & ring_mask) + c;
+            if (NL == 2)
+                atomicAdd(reinterpret_cast<unsigned int *>(cell), (unsigned int)v[r]);
+            else
+                atomicAdd(reinterpret_cast<unsigned long long *>(cell), (unsigned long long)(long long)v[r]);
+        }
+    }
+    dma_drain();
     __syncthreads();
-    const int nF = (nOut + 31) >> 5;
-    for (int f = max(nT - lag, 0); f < nF; ++f) {
-        finish_tile(f);
-        __syncthreads();
-        flush_tile(f);
-        __syncthreads();
-    }
+    const int nF = (TSR_ABL & 48) ? 0 : (nOut + 31) >> 5;
+    const int f0 = max(nT - lag, 0);  // tiles < f0 went through phase AB inside the loop
+    if (!(TSR_ABL & 4))
+        for (int f = f0; f < nF; ++f)
+            for (int j = 0; j < njs; ++j) fin_ab(f, j);
+    __syncthreads();
+    if (!(TSR_ABL & 4))
+        for (int f = max(f0 - 1, 0); f < nF; ++f)  // tile f0-1 still awaits its phase C
+            if (wave == (f & (kWaves - 1))) fin_c(f);
 }
 
 // (G > 1) sum the fragments of every template, then the reference epilogue.
@@ -756,13 +716,13 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
     int tile_bytes = 32 * SB + std::max(0, k_span + 16 - SB);
     tile_bytes = (tile_bytes + 1023) / 1024 * 1024;
     // a frame is final once the tile holding its last tap (Lmax-1 rows further) is emitted;
-    // emission trails the MFMAs by one tile and finishing trails emission by one barrier,
-    // hence the ring spans lag + 4 tiles
+    // emission trails the MFMAs by one tile, finishing trails emission by one barrier and the
+    // utt_end row of tile t+2 is DMA'd while tile t-lag-2 is finished: lag + 5 tiles
     int lag = (bank->Lmax - 1 + 31) / 32;
     int ring = 32;
-    while (ring < 32 * (lag + 4)) ring *= 2;
-    const size_t lds = (size_t)3 * tile_bytes + (size_t)kMaxSlots * sizeof(SlotMeta) + 128 * 4 +
-                       (size_t)(ring + 64) * 4 +
+    while (ring < 32 * (lag + 5)) ring *= 2;
+    const size_t lds = (size_t)3 * tile_bytes + (size_t)kMaxSlots * sizeof(SlotMeta) +
+                       (size_t)(ring + 64) * 4 + (size_t)ring * 8 +
                        (size_t)(fb->max_slots + 1) * (ring + 33) * (NL == 2 ? 4 : 8) + 16;
     if (lds > 160 * 1024) {
         tsr_set_error("TSR_FAST: D=%lld, Lmax=%d need %zu bytes of LDS", (long long)bank->D, bank->Lmax, lds);
