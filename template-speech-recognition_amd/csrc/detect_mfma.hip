@@ -130,7 +130,9 @@ template <> struct RingT<2> { using type = int; };
 
 // NKB: K-blocks (of 32 features) per wave; NL: int8 limbs per weight (2: 16-bit fixed point,
 // int32 ring; 3: 23-bit fixed point, int64 ring); FLAT: LDS row stride == resident row stride.
-template <int NKB, int NL, bool FLAT>
+// MODE: 0 = max score + template id per frame, 1 = every template's score, 2 = partial raw
+// scores per template fragment (several column groups; frag_epilogue_kernel finishes them).
+template <int NKB, int NL, bool FLAT, int MODE>
 __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a)
 {
     using ring_t = typename RingT<NL>::type;
@@ -151,7 +153,9 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
     // two) PLUS 32 overflow cells: a tile's 32 rows are emitted at cell (first & mask) + 0..31
     // without wrapping, so the 16 atomics of a lane share one address register and differ
     // only in their immediate offset; the finishing pass folds overflow cell i into cell i.
-    auto xbuf = [&](int t) { return smem + (t % 3) * a.tile_bytes; };
+    const unsigned xb0 = lds_addr(smem), xb_end = xb0 + 3 * a.tile_bytes;
+    auto xnext = [&](unsigned x) { return x + a.tile_bytes == xb_end ? xb0 : x + a.tile_bytes; };
+    auto lds_ptr = [&](unsigned addr) { return smem + (addr - xb0); };
     SlotMeta *meta = reinterpret_cast<SlotMeta *>(smem + 3 * a.tile_bytes);
     int *uend_ring = reinterpret_cast<int *>(meta + kMaxSlots);  // utt_end of the frames in flight
     unsigned long long *maxring = reinterpret_cast<unsigned long long *>(uend_ring + a.ring + 64);
@@ -187,21 +191,28 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
     // one DMA instruction moves 1 KiB (64 lanes x 16 B); wave w issues pieces w, w+8, ...
     const int n_pieces = a.tile_bytes >> 10;
     const int slots_per_row = a.SB >> 4, src_slots = a.Dp >> 4;
-    auto stage = [&](int t, uint8_t *dst) {
+    (void)slots_per_row;
+    (void)src_slots;
+    // per-lane byte offset of DMA piece `pc` inside a tile of the resident corpus
+    auto piece_src_off = [&](int pc) -> int {
+        const int chunk = pc * 64 + lane;  // 16-byte slot of the LDS tile
+        if (FLAT) return chunk * 16;
+        // LDS rows carry one extra (unused) slot to keep the stride odd
+        const int row = chunk / slots_per_row, c16 = chunk - row * slots_per_row;
+        return row * a.Dp + min(c16, src_slots - 1) * 16;
+    };
+    // (kept in registers only when there are registers to spare)
+    const int src_off0 = NL == 2 ? piece_src_off(wave) : 0, src_off1 = NL == 2 ? piece_src_off(wave + kWaves) : 0;
+    const uint8_t *const seg_src = a.X + (int64_t)o0 * a.Dp;
+    const int tile_src_bytes = 32 * a.Dp;
+    auto stage = [&](int t, unsigned dst) {
         if (TSR_ABL & 8) return;
-        const uint8_t *src_tile = a.X + ((int64_t)o0 + 32 * (int64_t)t) * a.Dp;
-        const unsigned dst0 = lds_addr(dst);
-        for (int pc = wave; pc < n_pieces; pc += kWaves) {
-            const int chunk = pc * 64 + lane;  // 16-byte slot of the LDS tile
-            const uint8_t *src;
-            if (FLAT) {
-                src = src_tile + chunk * 16;
-            } else {  // LDS rows carry one extra (unused) slot to keep the stride odd
-                const int row = chunk / slots_per_row, c16 = chunk - row * slots_per_row;
-                src = src_tile + (int64_t)row * a.Dp + min(c16, src_slots - 1) * 16;
-            }
-            lds_dma16(src, __builtin_amdgcn_readfirstlane(dst0 + pc * 1024));
-        }
+        const uint8_t *src_tile = seg_src + (int64_t)t * tile_src_bytes;
+        if (wave < n_pieces) lds_dma16(src_tile + (NL == 2 ? src_off0 : piece_src_off(wave)), dst + wave * 1024);
+        if (wave + kWaves < n_pieces)
+            lds_dma16(src_tile + (NL == 2 ? src_off1 : piece_src_off(wave + kWaves)), dst + (wave + kWaves) * 1024);
+        for (int pc = wave + 2 * kWaves; pc < n_pieces; pc += kWaves)  // wide rows only
+            lds_dma16(src_tile + piece_src_off(pc), dst + pc * 1024);
         // the utt_end values of the tile's 32 frames ride along (4-byte DMA, one wave): the
         // finishing pass must not issue register loads, or hipcc drains the tile DMA early
         if (wave == kWaves - 1 && lane < 32)
@@ -222,61 +233,79 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
     // reference's strict '>' = first maximum).
     // Phase C (wave f % 8, one iteration later): decode the tile's 32 keys, lanes 0..31 store
     // scores and lanes 32..63 ids -- two coalesced 128-byte stores.
-    auto fin_ab = [&](int f, int j) {
+    struct FinA {  // phase A: everything phase B needs from LDS, fetched a few steps ahead
+        ring_t q;
+        SlotMeta sm;
+        int uend;
+    };
+    auto fin_a = [&](int f, int j, FinA &fa) {
+        const int s = wave + 16 * j + 8 * half;
+        const int ridx = (f * 32 + (lane & 31)) & ring_mask;
+        ring_t *cell = ring + min(s, nslots) * rstride + ridx;  // spare row when s is past the end
+        fa.q = *cell;
+        *cell = 0;
+        if (((32 * f) & ring_mask) == 0) {  // wave-uniform: this tile owns the overflow cells
+            fa.q += cell[a.ring];
+            cell[a.ring] = 0;
+        }
+        fa.sm = meta[min(s, kMaxSlots - 1)];
+        fa.uend = uend_ring[ridx];
+    };
+    auto fin_b = [&](int f, int j, const FinA &fa) {
         const int s = wave + 16 * j + 8 * half;
         const int prel = f * 32 + (lane & 31);
         const int ridx = prel & ring_mask;
-        ring_t *cell = ring + min(s, nslots) * rstride + ridx;  // spare row when s is past the end
-        ring_t q = *cell;
-        *cell = 0;
-        if (((32 * f) & ring_mask) == 0) {  // wave-uniform: this tile owns the overflow cells
-            q += cell[a.ring];
-            cell[a.ring] = 0;
-        }
-        const SlotMeta sm = meta[min(s, kMaxSlots - 1)];
-        const int uend = uend_ring[ridx];
-        const bool valid = prel < nOut && s < nslots;
+        const SlotMeta sm = fa.sm;
         const int64_t p = (int64_t)o0 + prel;
         float x;
         if (NL == 2) {
-            x = (float)q * sm.inv_scale;  // |q| < 2^31: one rounding
+            x = (float)fa.q * sm.inv_scale;  // |q| < 2^31: one rounding
         } else {
             // exact int64 -> correctly rounded f32: q = hi*2^24 + lo, |hi| < 2^13, 0 <= lo < 2^24,
             // both exact in f32, a single rounding in the fma
-            const long long qq = q;
+            const long long qq = fa.q;
             x = __builtin_fmaf((float)(int)(qq >> 24), 16777216.0f, (float)((unsigned)qq & 0xffffffu)) *
                 sm.inv_scale;
         }
-        if (a.raw_frag) {  // several column groups: partial sums, finished by the epilogue kernel
-            if (valid) a.raw_frag[(int64_t)sm.tf * a.P + p] = x;
+        if (MODE == 2) {  // several column groups: partial sums, finished by the epilogue kernel
+            if (prel < nOut && s < nslots) a.raw_frag[(int64_t)sm.tf * a.P + p] = x;
             return;
         }
         // tail t > T - L_m scores 0 (+ c_m), as the reference's zero tail does
-        const float raw = (p + sm.L <= uend) ? x : 0.0f;
+        const float raw = (p + sm.L <= fa.uend) ? x : 0.0f;
         const float sc = raw + sm.cf;
-        if (a.all && valid) a.all[(int64_t)sm.tf * a.P + p] = sc;
-        if (a.scores && s < nslots) {
-            unsigned u = __builtin_bit_cast(unsigned, sc);
-            u ^= (unsigned)((int)u >> 31) | 0x80000000u;  // monotone map f32 -> u32
-            atomicMax(&maxring[ridx], ((unsigned long long)u << 32) | (unsigned)~sm.tf);
+        if (MODE == 1) {
+            if (prel < nOut && s < nslots) a.all[(int64_t)sm.tf * a.P + p] = sc;
+            return;
         }
+        unsigned u = __builtin_bit_cast(unsigned, sc);
+        u ^= (unsigned)((int)u >> 31) | 0x80000000u;  // monotone map f32 -> u32
+        // idle lanes (slot past the end) contribute key 0, the identity of max: no branch
+        const unsigned long long key = (s < nslots) ? (((unsigned long long)u << 32) | (unsigned)~sm.tf) : 0ull;
+        atomicMax(&maxring[ridx], key);
     };
-    auto fin_c = [&](int f) {
-        if (a.raw_frag || !a.scores) return;
-        const int prel = f * 32 + (lane & 31);
-        const int ridx = prel & ring_mask;
+    auto fin_ab = [&](int f, int j) {
+        FinA fa;
+        fin_a(f, j, fa);
+        fin_b(f, j, fa);
+    };
+    auto fin_c_read = [&](int f) -> unsigned long long {
+        if (MODE != 0) return 0;
+        const int ridx = (f * 32 + (lane & 31)) & ring_mask;
         const unsigned long long key = maxring[ridx];
         __builtin_amdgcn_wave_barrier();  // both halves have read the cell before it is reset
         if (half == 0) maxring[ridx] = 0;
-        if (prel < nOut) {
-            const int64_t p = (int64_t)o0 + prel;
-            unsigned u = (unsigned)(key >> 32);
-            u ^= (~(unsigned)((int)u >> 31)) | 0x80000000u;  // inverse of the monotone map
-            if (half == 0)
-                a.scores[p] = __builtin_bit_cast(float, u);
-            else
-                a.ids[p] = (int)~(unsigned)key;
-        }
+        return key;
+    };
+    auto fin_c_store = [&](int f, unsigned long long key) {
+        if (MODE != 0) return;
+        const int prel = f * 32 + (lane & 31);
+        unsigned u = (unsigned)(key >> 32);
+        u ^= (~(unsigned)((int)u >> 31)) | 0x80000000u;  // inverse of the monotone map
+        // lanes 0..31 store the score bits, lanes 32..63 the ids: one predicated dword store
+        int *dst = (half == 0 ? reinterpret_cast<int *>(a.scores) : a.ids) + (int64_t)o0 + prel;
+        const int val = half == 0 ? (int)u : (int)~(unsigned)key;
+        if (prel < nOut) *dst = val;
     };
     const int njs = (nslots - wave + 15) / 16;  // slot pairs this wave walks (wave-uniform)
 
@@ -296,7 +325,11 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
     // sched_barrier keeps hipcc from clustering the VALU/LDS work behind the last MFMA.
     constexpr int H = NKB / 2;                            // K-block step that opens with the barrier
     constexpr int PF = (NL == 2 ? 4 : 1) < (NKB - H) ? (NL == 2 ? 4 : 1) : (NKB - H);  // queue depth
-    constexpr int kAB = H + (NKB - H) / 3, kC = H + (2 * (NKB - H)) / 3;
+    // finishing phases: A (LDS reads) two steps ahead of B (arithmetic + max-key atomic); C reads
+    // its keys one step ahead of the stores
+    // (three limbs leave no registers to carry phase A's values across steps: same step there)
+    constexpr int kFA = H, kFB = (NL == 2 && H + 2 < NKB) ? H + 2 : H;
+    constexpr int kCR = (H + 3 < NKB) ? H + 3 : NKB - 1, kCS = (NL == 2 && H + 4 < NKB) ? H + 4 : kCR;
     const int lag = a.lag + 2;
     // a wave whose 32 columns are all real taps can skip the range check on tiles whose
     // targets [32 te - (Lmax-1), 32 te + 35] all lie inside the segment's outputs
@@ -305,20 +338,25 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
     i32x4 aq[PF];
     i32x16 v = {};
 
+    unsigned x_cur = xb0;  // LDS address of tile t; t+1 and t+2 follow in the 3-buffer rotation
     auto tile_iter = [&](int t, bool do_emit, bool interior, int fin) {
         i32x16 acc[NL];
 #pragma unroll
         for (int l = 0; l < NL; ++l) acc[l] = (i32x16){};
-        const uint8_t *xa = xbuf(t) + a_off, *xn = xbuf(t + 1) + a_off;
+        const unsigned x_nxt = xnext(x_cur);
+        const uint8_t *xa = lds_ptr(x_cur) + a_off, *xn = lds_ptr(x_nxt) + a_off;
         const int first = kl + 32 * (t - 1);  // target frame of accumulator row 0 (tile t-1)
         ring_t *const cell0 = my_row + (first & ring_mask);
         ring_t *const dcell0 = dummy_row + (first & ring_mask);
+        FinA fa = {};
+        unsigned long long ckey = 0;
+        const bool c_wave = fin >= 1 && wave == ((fin - 1) & (kWaves - 1));
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             if (kb == H) {
                 if (!(TSR_ABL & 128)) dma_drain();  // this wave's pieces of tile t+1 (and its stores) are done
                 if (!(TSR_ABL & 64)) __syncthreads();  // tile t+1 landed; tiles <= t-2 fully emitted
-                if (t + 2 < nT) stage(t + 2, xbuf(t + 2));
+                if (t + 2 < nT) stage(t + 2, xnext(x_nxt));
             }
             const i32x4 av = aq[0];
 #pragma unroll
@@ -349,9 +387,13 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
                 }
             }
             if (!(TSR_ABL & 4)) {
-                if (kb == kAB && fin >= 0)
-                    for (int j = 0; j < njs; ++j) fin_ab(fin, j);
-                if (kb == kC && fin >= 1 && wave == ((fin - 1) & (kWaves - 1))) fin_c(fin - 1);
+                if (kb == kFA && fin >= 0 && njs > 0) fin_a(fin, 0, fa);
+                if (kb == kFB && fin >= 0) {
+                    if (njs > 0) fin_b(fin, 0, fa);
+                    for (int j = 1; j < njs; ++j) fin_ab(fin, j);  // more than 16 slots
+                }
+                if (kb == kCR && c_wave) ckey = fin_c_read(fin - 1);
+                if (kb == kCS && c_wave) fin_c_store(fin - 1, ckey);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -366,15 +408,16 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
             for (int l = NL - 2; l >= 0; --l) x = x * 256 + acc[l][r];
             v[r] = x;
         }
+        x_cur = x_nxt;
     };
 
-    if (nT > 0) stage(0, xbuf(0));
-    if (nT > 1) stage(1, xbuf(1));
+    if (nT > 0) stage(0, xb0);
+    if (nT > 1) stage(1, xnext(xb0));
     dma_drain();
     __syncthreads();  // ring/meta initialised, tiles 0 and 1 landed
     if (nT > 0) {
 #pragma unroll
-        for (int i = 0; i < PF; ++i) aq[i] = *reinterpret_cast<const i32x4 *>(xbuf(0) + a_off + i * 32);
+        for (int i = 0; i < PF; ++i) aq[i] = *reinterpret_cast<const i32x4 *>(smem + a_off + i * 32);
     }
     for (int t = 0; t < nT; ++t) {
         const bool interior = no_pad && 32 * (t - 1) >= lmax1 && 32 * (t - 1) + 35 < nOut;
@@ -406,7 +449,7 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
     __syncthreads();
     if (!(TSR_ABL & 4))
         for (int f = max(f0 - 1, 0); f < nF; ++f)  // tile f0-1 still awaits its phase C
-            if (wave == (f & (kWaves - 1))) fin_c(f);
+            if (wave == (f & (kWaves - 1))) fin_c_store(f, fin_c_read(f));
 }
 
 // (G > 1) sum the fragments of every template, then the reference epilogue.
@@ -455,15 +498,23 @@ int upload(tsr_ctx *ctx, T **dptr, const std::vector<T> &v)
     return TSR_OK;
 }
 
+template <int NKB, int NL, bool FLAT, int MODE>
+int launch4(tsr_ctx *ctx, const FastArgs &args, int grid, size_t lds)
+{
+    TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fast_bank_kernel<NKB, NL, FLAT, MODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((fast_bank_kernel<NKB, NL, FLAT, MODE>), dim3(grid), dim3(kThreads), lds,
+                       ctx->stream, args);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+
 template <int NKB, int NL, bool FLAT>
 int launch3(tsr_ctx *ctx, const FastArgs &args, int grid, size_t lds)
 {
-    TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fast_bank_kernel<NKB, NL, FLAT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((fast_bank_kernel<NKB, NL, FLAT>), dim3(grid), dim3(kThreads), lds, ctx->stream,
-                       args);
-    TSR_HIP(hipGetLastError());
-    return TSR_OK;
+    if (args.raw_frag) return launch4<NKB, NL, FLAT, 2>(ctx, args, grid, lds);
+    if (args.all) return launch4<NKB, NL, FLAT, 1>(ctx, args, grid, lds);
+    return launch4<NKB, NL, FLAT, 0>(ctx, args, grid, lds);
 }
 
 template <int NKB>
