@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- scored frames/s of the template-scoring hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode fast|exact]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode fast|fast24|exact]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -79,7 +79,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", choices=["auto", "fast", "exact"], default=os.environ.get("TSR_BENCH_MODE", "auto"))
+    ap.add_argument("--mode", choices=["auto", "fast", "fast24", "exact"],
+                    default=os.environ.get("TSR_BENCH_MODE", "auto"),
+                    help="fast: MFMA, 16-bit fixed-point weights (2 int8 limbs); fast24: 23-bit "
+                         "(3 limbs); exact: f32 VALU in the reference's summation order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -118,7 +121,8 @@ def main():
             if e.status != 4:
                 raise
             args.mode = "exact"
-    flags = tsr_hip.TSR_FAST if args.mode == "fast" else tsr_hip.TSR_EXACT
+    flags = {"fast": tsr_hip.TSR_FAST, "fast24": tsr_hip.TSR_FAST | tsr_hip.TSR_W24,
+             "exact": tsr_hip.TSR_EXACT}[args.mode]
     frames = int(corpus["offsets"][-1])
 
     def barrier():
@@ -163,6 +167,24 @@ def main():
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         sumL = CFG["M"] * CFG["L"]
         alg_flops = 2.0 * CFG["F"] * CFG["E"] * sumL * (CFG["T"] - CFG["L"] + 1) * CFG["N"]
+        hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+               "alg_bytes_per_launch": alg_bytes}
+        if args.mode == "exact":
+            # VALU-bound by construction (sequential f32 adds); the HBM roofline is what the
+            # contract asks to be reported against
+            roofline = dict(hbm, bound="hbm", traffic=traffic, kernel_ms_per_launch=per_launch_s * 1e3,
+                            valu_tflops=alg_flops / per_launch_s / 1e12, valu_peak_tflops=VALU_F32_PEAK_TFLOPS)
+        else:
+            # 425 flop/B at M=8 vs a machine balance of ~600 int8-op/B -- close to the
+            # ridge, and each algorithmic MAC costs 2 (3) int8 limb-MACs, so the matrix cores bind
+            tops = alg_flops / per_launch_s / 1e12
+            roofline = {"bound": "mfma", "achieved": tops, "peak": MFMA_I8_PEAK_TOPS, "unit": "TFLOP/s",
+                        "frac": tops / MFMA_I8_PEAK_TOPS, "traffic": traffic,
+                        "kernel_ms_per_launch": per_launch_s * 1e3,
+                        "alg_flops_per_launch": alg_flops,
+                        "limb_macs_per_alg_mac": 2 if args.mode == "fast" else 3,
+                        "peak_note": "dense int8 MFMA = 2x the ~2.5 PF bf16 dense peak (MI355X_MICROARCH.md)",
+                        "hbm": hbm}
         out = {
             "metric": "scored frames/sec (whole node) + achieved HBM GB/s vs roofline",
             "value": frames * world * args.steps / wall,
@@ -170,21 +192,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "i8 x3 limbs (i32 accumulate)" if args.mode == "fast" else "f32",
+            "dtype": {"fast": "i8 (2 limbs, i32 accumulate)", "fast24": "i8 (3 limbs, i32 accumulate)",
+                      "exact": "f32"}[args.mode],
             "data": "synthetic",
             "config": {"workload": "config 2: %d utterances x %d frames x D=%d binary features, "
                                    "%d-template bank, L=%d, per GPU; max-score + template id per frame"
                                    % (CFG["N"], CFG["T"], CFG["F"] * CFG["E"], CFG["M"], CFG["L"]),
                        "mode": args.mode, "frames_per_gpu": frames, "parallelism": "utterance-sharded x%d" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms_per_launch": per_launch_s * 1e3,
-                         "alg_bytes_per_launch": alg_bytes},
-            "compute": {"alg_tflops": alg_flops / per_launch_s / 1e12,
-                        "peak": MFMA_I8_PEAK_TOPS if args.mode == "fast" else VALU_F32_PEAK_TFLOPS,
-                        "unit": "TOP/s (int8 MFMA, dense)" if args.mode == "fast" else "TFLOP/s (f32 VALU)",
-                        "note": "algorithmic flops = 2*D*sum(L_m) per valid window (SURVEY 8(d)); "
-                                "the int8 path spends 3 limb-MACs per algorithmic MAC"},
+            "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(corpus)
