@@ -96,20 +96,20 @@ def main():
 
     ctx = tsr_hip.Context(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # launched by torch.distributed.run
         import torch.distributed as dist  # host control plane only (gloo, CPU tensors)
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     # ---- data: every rank its own utterances, one bank for all ----------------------
     corpus = synth.corpus(2 + 1000 * rank, **CFG)
-    if world > 1:
-        ids = [tsr_hip.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        ctx.dist_init(ids[0], world, rank)
+    if dist is not None:
+        from tsr_hip import dist as tdist
+        ctx.dist_init(tdist.exchange_unique_id(dist, tsr_hip.unique_id), world, rank)
         if rank != 0:  # same geometry, weights to be overwritten by rank 0's
-            corpus["bank"] = tuple((np.zeros_like(W), 0.0) for W, _ in corpus["bank"])
+            corpus["bank"] = tdist.placeholder_bank([W.shape[0] for W, _ in corpus["bank"]],
+                                                    corpus["bank"][0][0].shape[1:])
     bank = tsr_hip.Bank(corpus["bank"], ctx=ctx)
-    if world > 1:
+    if dist is not None:
         bank.broadcast(0)  # RCCL over xGMI; the only collective on this path
     dev_corpus = tsr_hip.Corpus(corpus["feats"], corpus["offsets"], ctx=ctx)
     if args.mode == "auto":  # the MFMA path when this build has it, else the exact VALU path
@@ -141,10 +141,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     if dist is not None:
-        import torch
-        t = torch.tensor([wall, kernel_ms], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, kernel_ms = float(t[0]), float(t[1])
+        wall, kernel_ms = tdist.max_over_ranks(dist, wall, kernel_ms)
 
     # ---- parity spot check on what was just computed (rank 0, oracle as checker) -----
     scores, ids_ = dev_corpus.download()

@@ -733,10 +733,26 @@ rccl_api g_rccl;
 static int rccl_load()
 {
     if (g_rccl.h) return TSR_OK;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // Take the librccl that sits next to the HIP runtime this process actually uses: a process
+    // may hold two ROCm stacks (e.g. /opt/rocm and the one bundled with a torch wheel, same
+    // sonames), and an RCCL built against the other runtime fails in ncclCommInitRank.
+    std::string dir;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &info) && info.dli_fname) {
+        dir = info.dli_fname;
+        const size_t slash = dir.rfind('/');
+        dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
+    }
+    std::vector<std::string> names;
+    if (!dir.empty()) {
+        names.push_back(dir + "librccl.so.1");
+        names.push_back(dir + "librccl.so");
+    }
+    names.push_back("librccl.so.1");
+    names.push_back("librccl.so");
     void *h = nullptr;
-    for (const char *n : names)
-        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    for (const std::string &n : names)
+        if ((h = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL))) break;
     if (!h) {
         tsr_set_error("RCCL: cannot dlopen librccl (%s)", dlerror());
         return TSR_ERR_RCCL;

@@ -1,34 +1,43 @@
-"""Build libtsr_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+"""Build libtsr_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+Sources are compiled to objects one by one (only the stale ones) and linked."""
 import os
 import subprocess
 import sys
 
 PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(PKG, "lib", "obj")
 LIB = os.path.join(PKG, "lib", "libtsr_hip.so")
 SOURCES = ["tsr_api.hip", "detect_exact.hip", "detect_mfma.hip", "parts.hip"]
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wextra", "-Wno-unused-parameter"]
+HEADERS = [os.path.join(CSRC, "tsr_internal.h"), os.path.join(os.path.dirname(PKG), "include", "tsr.h")]
 
 
-def stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + \
-           [os.path.join(os.path.dirname(PKG), "include", "tsr.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+def _newer(path, deps):
+    return not os.path.exists(path) or any(os.path.getmtime(d) > os.path.getmtime(path) for d in deps)
 
 
 def build(force=False, verbose=False):
-    if not force and not stale():
-        return LIB
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    objs, procs = [], []
+    for src in SOURCES:
+        s, o = os.path.join(CSRC, src), os.path.join(OBJ, src + ".o")
+        objs.append(o)
+        if force or _newer(o, [s] + HEADERS):
+            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    if force or procs or _newer(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return LIB
 
 

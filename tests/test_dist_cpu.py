@@ -1,0 +1,82 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU host logic: utterance sharding, the RCCL
+unique-id hand-over, placeholder banks, max-over-ranks timing and score gathering.  The GPU
+work itself needs no collective; what is exercised here is everything around it that bench.py
+relies on for N > 1."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "template-speech-recognition_amd"))
+
+from tsr_hip import dist as tdist  # noqa: E402
+
+
+def test_shard_utterances_balanced_and_contiguous():
+    rng = np.random.default_rng(0)
+    lengths = rng.integers(50, 400, size=1000)
+    for world in (1, 2, 3, 8):
+        b = tdist.shard_utterances(lengths, world)
+        assert b[0] == 0 and b[-1] == 1000 and np.all(np.diff(b) >= 0) and len(b) == world + 1
+        frames = np.array([lengths[b[r]:b[r + 1]].sum() for r in range(world)])
+        assert frames.sum() == lengths.sum()
+        assert frames.max() - frames.min() <= 2 * lengths.max()
+    assert tdist.shard_utterances([], 4).tolist() == [0, 0, 0, 0, 0]
+    assert tdist.shard_utterances([7], 2).tolist() in ([0, 0, 1], [0, 1, 1])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        uid = tdist.exchange_unique_id(dist, lambda: bytes(range(128)))
+        assert uid == bytes(range(128))
+        # utterance-sharded scoring with a stand-in scorer (per-frame sum): every rank handles
+        # its own utterances, nothing is exchanged until the gather
+        rng = np.random.default_rng(5)
+        lengths = rng.integers(3, 30, size=41)
+        feats = rng.integers(0, 2, size=(int(lengths.sum()), 6)).astype(np.uint8)
+        offs = np.concatenate(([0], np.cumsum(lengths)))
+        b = tdist.shard_utterances(lengths, world)
+        lo, hi = int(offs[b[rank]]), int(offs[b[rank + 1]])
+        local_scores = feats[lo:hi].sum(1).astype(np.float32)
+        local_ids = np.full(hi - lo, rank, np.int32)
+        s, i = tdist.gather_scores(dist, local_scores, local_ids, offs)
+        assert np.array_equal(s, feats.sum(1).astype(np.float32))
+        assert np.array_equal(i[:int(offs[b[1]])], np.zeros(int(offs[b[1]]), np.int32))
+        mx = tdist.max_over_ranks(dist, float(rank + 1), 10.0 - rank)
+        assert mx == [float(world), 10.0]
+        pb = tdist.placeholder_bank([3, 5], (4, 2))
+        assert [w.shape for w, _ in pb] == [(3, 4, 2), (5, 4, 2)] and not pb[0][0].any()
+        dist.barrier()
+        out.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        out.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(out.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == {0: "ok", 1: "ok"}, res
