@@ -154,6 +154,16 @@ int tsr_part_features(tsr_ctx *ctx, const tsr_parts *parts, const uint8_t *X, in
                       int64_t X1, int threshold, int fast, int r0, int r1, const uint8_t *graph,
                       int g0, int g1, uint8_t *out, int64_t *argmax_out);
 
+/* The same chain over a whole device-resident corpus of edge maps (D = X1*E per frame): returns a
+ * NEW corpus of part maps (D = O1*K per frame, utterance n has ceil((T_n-P0+1)/g0) frames) that
+ * tsr_corpus_score consumes directly -- BASELINE config 3, no host round trip. */
+int tsr_corpus_part_features(tsr_ctx *ctx, const tsr_parts *parts, const tsr_corpus *edges,
+                             int threshold, int fast, int r0, int r1, const uint8_t *graph, int g0,
+                             int g1, tsr_corpus **out);
+/* Read back a corpus: feature bytes u8 [sum T_n, D]; its shape (frame_offsets i64 [N+1], may be NULL). */
+int tsr_corpus_download_feats(tsr_ctx *ctx, const tsr_corpus *corpus, uint8_t *feats);
+int tsr_corpus_shape(const tsr_corpus *corpus, int64_t *N, int64_t *D, int64_t *frame_offsets);
+
 /* ---- multi-GPU: utterances shard across ranks, the bank is broadcast once ----- */
 /* One process per GPU.  Rank 0 calls tsr_dist_unique_id and hands the 128 bytes
  * to the other ranks over any host channel; every rank then calls

@@ -72,7 +72,8 @@ struct SlotMeta {  // one template fragment handled by a workgroup (LDS copy, 16
 struct FastArgs {
     const uint8_t *X;        // [P + slack][Dp] bytes in {0,1}
     int Dp;                  // resident row stride (multiple of 16)
-    int SB;                  // LDS row stride: odd multiple of 16 >= Dp
+    int SB;                  // LDS row stride: odd multiple of 16 >= the bytes copied per row
+    int src_slots;           // 16-byte slots copied per frame (whole row, or one K-phase of it)
     int tile_bytes;          // bytes one LDS tile buffer holds (multiple of 1024)
     int G, CT, KS;           // column groups; column tiles and K-slices per workgroup
     int nseg;                // frame-stream segments (workgroups per column group)
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
     // ---- frame tiles: tile t = rows [o0 + 32 t, +32), copied by LDS-DMA --------------------
     // one DMA instruction moves 1 KiB (64 lanes x 16 B); wave w issues pieces w, w+8, ...
     const int n_pieces = a.tile_bytes >> 10;
-    const int slots_per_row = a.SB >> 4, src_slots = a.Dp >> 4;
+    const int slots_per_row = a.SB >> 4, src_slots = a.src_slots;
     (void)slots_per_row;
     (void)src_slots;
     // per-lane byte offset of DMA piece `pc` inside a tile of the resident corpus
@@ -454,8 +455,8 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
 
 // (G > 1) sum the fragments of every template, then the reference epilogue.
 __global__ __launch_bounds__(256) void frag_epilogue_kernel(
-    const float *__restrict__ raw_frag, int64_t P, int M, const int32_t *__restrict__ frag_first,
-    const int32_t *__restrict__ L, const float *__restrict__ cf,
+    const float *__restrict__ raw_frag, int64_t P, int M, const int32_t *__restrict__ frag_ptr,
+    const int32_t *__restrict__ frag_idx, const int32_t *__restrict__ L, const float *__restrict__ cf,
     const int32_t *__restrict__ utt_end, float *__restrict__ scores, int32_t *__restrict__ ids,
     float *__restrict__ all)
 {
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(256) void frag_epilogue_kernel(
     int besti = 0;
     for (int m = 0; m < M; ++m) {
         float r = 0.0f;
-        for (int f = frag_first[m]; f < frag_first[m + 1]; ++f) r += raw_frag[(int64_t)f * P + p];
+        for (int f = frag_ptr[m]; f < frag_ptr[m + 1]; ++f) r += raw_frag[(int64_t)frag_idx[f] * P + p];
         if (p + L[m] > end) r = 0.0f;
         const float v = r + cf[m];
         if (all) all[(int64_t)m * P + p] = v;
@@ -483,8 +484,10 @@ struct FastBank {
     int NL = 0;  // int8 limbs per weight
     int NKB = 0, KS = 0, CT = 0, G = 0, nkb_total = 0, n_coltiles = 0, n_frag = 0;
     i32x4 *d_Wl = nullptr;
+    int n_phase = 1;       // K-phases: feature ranges of NKB*32, one kernel pass each
+    size_t wl_phase = 0;   // i32x4 elements of Wl per phase
     int32_t *d_col_slot = nullptr, *d_col_tau = nullptr, *d_g_nslots = nullptr;
-    int32_t *d_frag_first = nullptr;
+    int32_t *d_frag_ptr = nullptr, *d_frag_idx = nullptr;
     SlotMeta *d_slots = nullptr;
     int max_slots = 0;
 };
@@ -536,7 +539,8 @@ static void fast_bank_free_one(tsr_bank *bank, int which)
     (void)hipFree(fb->d_col_slot);
     (void)hipFree(fb->d_col_tau);
     (void)hipFree(fb->d_g_nslots);
-    (void)hipFree(fb->d_frag_first);
+    (void)hipFree(fb->d_frag_ptr);
+    (void)hipFree(fb->d_frag_idx);
     (void)hipFree(fb->d_slots);
     delete fb;
     bank->fast[which] = nullptr;
@@ -555,13 +559,12 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int NL)
     const int M = bank->M;
     const int64_t D = bank->D;
     const int nkb_total = (int)((D + 31) / 32);
-    int KS = 1;
-    while (KS < kWaves && (nkb_total + KS - 1) / KS > kMaxNKB) KS *= 2;
-    const int NKB = (nkb_total + KS - 1) / KS;
-    if (NKB > kMaxNKB) {
-        tsr_set_error("TSR_FAST: D=%lld needs more than %d K-blocks per wave", (long long)D, kMaxNKB);
-        return TSR_ERR_UNSUPPORTED;
-    }
+    // Feature rows wider than one wave's register budget (kMaxNKB K-blocks) are split into
+    // K-phases: each phase is a complete kernel pass over its own feature range with its own
+    // register-stationary limbs; the phases' partial raw scores are summed by the epilogue.
+    const int n_phase = (nkb_total + kMaxNKB - 1) / kMaxNKB;
+    const int NKB = (nkb_total + n_phase - 1) / n_phase;
+    const int KS = 1;
     const int CT = kWaves / KS;
     const int64_t C = bank->sumL;
     const int n_coltiles = (int)((C + 31) / 32);
@@ -615,15 +618,17 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int NL)
         }
     }
     // ---- column groups -> fragment slots ------------------------------------------------------
+    // A fragment = (K-phase, column group, template): the unit of partial raw score a workgroup
+    // produces when the bank does not fit one pass of one workgroup.  Fragment rows are numbered
+    // phase-major; the epilogue sums a template's fragments in that fixed order.
     const int64_t Cpad = (int64_t)G * CT * 32;
     std::vector<int32_t> col_slot((size_t)Cpad, -1), col_tau((size_t)Cpad, 0);
-    std::vector<SlotMeta> slots((size_t)G * kMaxSlots);
+    std::vector<SlotMeta> slots((size_t)n_phase * G * kMaxSlots);
     memset(slots.data(), 0, slots.size() * sizeof(SlotMeta));
     std::vector<int32_t> g_nslots(G, 0);
-    std::vector<int> slot_m, slot_f;  // template / fragment of every slot, in creation order
-    int max_slots = 0;
-    std::vector<std::vector<int>> frags_of(M);  // fragment ids per template, in column order
-    int n_frag = 0;
+    std::vector<std::vector<int>> frags_of(M);
+    int max_slots = 0, n_frag = 0;
+    const bool single = (n_phase == 1 && G == 1);
     for (int g = 0; g < G; ++g) {
         int nslots = 0, last_m = -1;
         for (int64_t c = (int64_t)g * CT * 32; c < std::min<int64_t>(C, (int64_t)(g + 1) * CT * 32); ++c) {
@@ -633,15 +638,6 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int NL)
                     tsr_set_error("TSR_FAST: more than %d templates share one column group", kMaxSlots);
                     return TSR_ERR_UNSUPPORTED;
                 }
-                SlotMeta &sm = slots[(size_t)g * kMaxSlots + nslots];
-                sm.inv_scale = (float)inv_scale[m];
-                sm.cf = (float)bank->c[m];
-                sm.L = bank->L[m];
-                sm.tf = -1;  // template id or fragment row, set once G is known to be 1 or more
-                slot_m.push_back(m);
-                slot_f.push_back(n_frag);
-                frags_of[m].push_back(n_frag);
-                ++n_frag;
                 ++nslots;
                 last_m = m;
             }
@@ -651,31 +647,42 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int NL)
         g_nslots[g] = nslots;
         max_slots = std::max(max_slots, nslots);
     }
-    {
-        size_t k = 0;
-        for (int g = 0; g < G; ++g)
-            for (int sidx = 0; sidx < g_nslots[g]; ++sidx, ++k)
-                slots[(size_t)g * kMaxSlots + sidx].tf = (G == 1) ? slot_m[k] : slot_f[k];
-    }
-    // fragment ids are handed out in column order, so a template's fragments are consecutive
-    std::vector<int32_t> frag_first(M + 1, 0);
+    for (int ph = 0; ph < n_phase; ++ph)
+        for (int g = 0; g < G; ++g) {
+            int sidx = -1, last_m = -1;
+            for (int64_t c = (int64_t)g * CT * 32; c < std::min<int64_t>(C, (int64_t)(g + 1) * CT * 32); ++c) {
+                const int m = col_tmpl[(size_t)c];
+                if (m == last_m) continue;
+                last_m = m;
+                ++sidx;
+                SlotMeta &sm = slots[((size_t)ph * G + g) * kMaxSlots + sidx];
+                sm.inv_scale = (float)inv_scale[m];
+                sm.cf = (float)bank->c[m];
+                sm.L = bank->L[m];
+                sm.tf = single ? m : n_frag;  // template id (fused outputs) or fragment row
+                frags_of[m].push_back(n_frag);
+                ++n_frag;
+            }
+        }
+    std::vector<int32_t> frag_ptr(M + 1, 0), frag_idx;
     for (int m = 0; m < M; ++m) {
-        frag_first[m] = frags_of[m].front();
-        frag_first[m + 1] = frags_of[m].back() + 1;
+        for (int f : frags_of[m]) frag_idx.push_back(f);
+        frag_ptr[m + 1] = (int32_t)frag_idx.size();
     }
-    // ---- limb fragments in register order: [coltile][ks][kb][limb][lane] x 16 bytes ------------
-    std::vector<i32x4> Wl((size_t)G * CT * KS * NKB * NL * 64);
+    // ---- limb fragments in register order: [phase][coltile][ks][kb][limb][lane] x 16 bytes ------
+    const size_t wl_phase = (size_t)G * CT * KS * NKB * NL * 64;
+    std::vector<i32x4> Wl(wl_phase * n_phase);
     memset(Wl.data(), 0, Wl.size() * sizeof(i32x4));
-    for (int64_t tile = 0; tile < (int64_t)G * CT; ++tile)
-        for (int ks = 0; ks < KS; ++ks)
+    for (int ph = 0; ph < n_phase; ++ph)
+        for (int64_t tile = 0; tile < (int64_t)G * CT; ++tile)
             for (int kb = 0; kb < NKB; ++kb)
                 for (int l = 0; l < NL; ++l)
                     for (int lane = 0; lane < 64; ++lane) {
                         const int64_t c = tile * 32 + (lane & 31);
                         if (c >= C) continue;
                         int8_t *dst = reinterpret_cast<int8_t *>(
-                            &Wl[((((size_t)tile * KS + ks) * NKB + kb) * NL + l) * 64 + lane]);
-                        const int64_t k0 = ((int64_t)ks * NKB + kb) * 32 + 16 * (lane >> 5);
+                            &Wl[ph * wl_phase + (((size_t)tile * NKB + kb) * NL + l) * 64 + lane]);
+                        const int64_t k0 = ((int64_t)ph * NKB + kb) * 32 + 16 * (lane >> 5);
                         for (int e = 0; e < 16; ++e)
                             if (k0 + e < D) dst[e] = limbs[((size_t)l * C + c) * D + k0 + e];
                     }
@@ -689,12 +696,15 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int NL)
     fb->n_coltiles = n_coltiles;
     fb->n_frag = n_frag;
     fb->max_slots = max_slots;
+    fb->n_phase = n_phase;
+    fb->wl_phase = wl_phase;
     bank->fast[NL - 2] = fb;
     int s = upload(ctx, &fb->d_Wl, Wl);
     if (s == TSR_OK) s = upload(ctx, &fb->d_col_slot, col_slot);
     if (s == TSR_OK) s = upload(ctx, &fb->d_col_tau, col_tau);
     if (s == TSR_OK) s = upload(ctx, &fb->d_g_nslots, g_nslots);
-    if (s == TSR_OK) s = upload(ctx, &fb->d_frag_first, frag_first);
+    if (s == TSR_OK) s = upload(ctx, &fb->d_frag_ptr, frag_ptr);
+    if (s == TSR_OK) s = upload(ctx, &fb->d_frag_idx, frag_idx);
     if (s == TSR_OK) s = upload(ctx, &fb->d_slots, slots);
     if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
     if (s != TSR_OK) fast_bank_free_one(bank, NL - 2);
@@ -759,11 +769,14 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
     const int64_t P = cp->P;
     if (P == 0) return TSR_OK;
     const int Dp = cp->Dp;
-    int SB = Dp;
-    if (((SB >> 4) & 1) == 0) SB += 16;  // odd number of 16-byte slots: conflict-free b128 reads
+    // LDS row: the bytes one pass needs of a frame (the whole resident row, or one K-phase of
+    // it), as an odd number of 16-byte slots so that b128 fragment reads are conflict-free
+    const int k_span = fb->KS * fb->NKB * 32;
+    int row_bytes = fb->n_phase == 1 ? Dp : k_span;  // source bytes copied per frame and pass
+    int SB = row_bytes;
+    if (((SB >> 4) & 1) == 0) SB += 16;
     // a tile buffer: 32 rows, rounded up to whole 1 KiB DMA pieces, plus the bytes the last
     // row's K-block reads may run past it (zero weights there, any finite byte is fine)
-    const int k_span = fb->KS * fb->NKB * 32;
     int tile_bytes = 32 * SB + std::max(0, k_span + 16 - SB);
     tile_bytes = (tile_bytes + 1023) / 1024 * 1024;
     // a frame is final once the tile holding its last tap (Lmax-1 rows further) is emitted;
@@ -785,58 +798,62 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
     nseg = (int)std::max<int64_t>(1, std::min<int64_t>(nseg, (P + min_rows - 1) / min_rows));
     TSR_TRY(build_plan(ctx, cp, nseg, bank->Lmax));
 
-    FastArgs a;
-    memset(&a, 0, sizeof a);
-    a.X = cp->d_feats;
-    a.Dp = Dp;
-    a.SB = SB;
-    a.tile_bytes = tile_bytes;
-    a.G = fb->G;
-    a.CT = fb->CT;
-    a.KS = fb->KS;
-    a.nseg = nseg;
-    a.seg = cp->d_plan;
-    a.Wl = fb->d_Wl;
-    a.col_slot = fb->d_col_slot;
-    a.col_tau = fb->d_col_tau;
-    a.slots = fb->d_slots;
-    a.g_nslots = fb->d_g_nslots;
-    a.utt_end = cp->d_utt_end;
-    a.P = P;
-    a.ring = ring;
-    a.lag = lag;
-    a.lmax1 = bank->Lmax - 1;
+    const bool fragments = fb->n_phase > 1 || fb->G > 1;
     void *raw_frag = nullptr;
-    if (fb->G > 1) {
-        TSR_TRY(tsr_scratch(ctx, 0, (size_t)fb->n_frag * P * sizeof(float), &raw_frag));
-        a.raw_frag = (float *)raw_frag;
-    } else {
-        a.scores = d_scores;
-        a.ids = d_ids;
-        a.all = d_all;
-    }
+    if (fragments) TSR_TRY(tsr_scratch(ctx, 0, (size_t)fb->n_frag * P * sizeof(float), &raw_frag));
     const int grid = nseg * fb->G;
-    const bool flat = (SB == Dp);
-    int s;
-    switch (fb->NKB) {
-    case 1: s = launch<1>(ctx, a, grid, lds, NL, flat); break;
-    case 2: s = launch<2>(ctx, a, grid, lds, NL, flat); break;
-    case 3: s = launch<3>(ctx, a, grid, lds, NL, flat); break;
-    case 4: s = launch<4>(ctx, a, grid, lds, NL, flat); break;
-    case 5: s = launch<5>(ctx, a, grid, lds, NL, flat); break;
-    case 6: s = launch<6>(ctx, a, grid, lds, NL, flat); break;
-    case 7: s = launch<7>(ctx, a, grid, lds, NL, flat); break;
-    case 8: s = launch<8>(ctx, a, grid, lds, NL, flat); break;
-    case 9: s = launch<9>(ctx, a, grid, lds, NL, flat); break;
-    case 10: s = launch<10>(ctx, a, grid, lds, NL, flat); break;
-    case 11: s = launch<11>(ctx, a, grid, lds, NL, flat); break;
-    default: s = launch<12>(ctx, a, grid, lds, NL, flat); break;
+    const bool flat = (SB == Dp) && fb->n_phase == 1;
+    for (int ph = 0; ph < fb->n_phase; ++ph) {
+        FastArgs a;
+        memset(&a, 0, sizeof a);
+        a.X = cp->d_feats + (size_t)ph * k_span;  // this phase's feature range of every row
+        a.Dp = Dp;
+        a.SB = SB;
+        a.src_slots = row_bytes >> 4;
+        a.tile_bytes = tile_bytes;
+        a.G = fb->G;
+        a.CT = fb->CT;
+        a.KS = fb->KS;
+        a.nseg = nseg;
+        a.seg = cp->d_plan;
+        a.Wl = fb->d_Wl + (size_t)ph * fb->wl_phase;
+        a.col_slot = fb->d_col_slot;
+        a.col_tau = fb->d_col_tau;
+        a.slots = fb->d_slots + (size_t)ph * fb->G * kMaxSlots;
+        a.g_nslots = fb->d_g_nslots;
+        a.utt_end = cp->d_utt_end;
+        a.P = P;
+        a.ring = ring;
+        a.lag = lag;
+        a.lmax1 = bank->Lmax - 1;
+        if (fragments) {
+            a.raw_frag = (float *)raw_frag;
+        } else {
+            a.scores = d_scores;
+            a.ids = d_ids;
+            a.all = d_all;
+        }
+        int s;
+        switch (fb->NKB) {
+        case 1: s = launch<1>(ctx, a, grid, lds, NL, flat); break;
+        case 2: s = launch<2>(ctx, a, grid, lds, NL, flat); break;
+        case 3: s = launch<3>(ctx, a, grid, lds, NL, flat); break;
+        case 4: s = launch<4>(ctx, a, grid, lds, NL, flat); break;
+        case 5: s = launch<5>(ctx, a, grid, lds, NL, flat); break;
+        case 6: s = launch<6>(ctx, a, grid, lds, NL, flat); break;
+        case 7: s = launch<7>(ctx, a, grid, lds, NL, flat); break;
+        case 8: s = launch<8>(ctx, a, grid, lds, NL, flat); break;
+        case 9: s = launch<9>(ctx, a, grid, lds, NL, flat); break;
+        case 10: s = launch<10>(ctx, a, grid, lds, NL, flat); break;
+        case 11: s = launch<11>(ctx, a, grid, lds, NL, flat); break;
+        default: s = launch<12>(ctx, a, grid, lds, NL, flat); break;
+        }
+        TSR_TRY(s);
     }
-    TSR_TRY(s);
-    if (fb->G > 1) {
+    if (fragments) {
         hipLaunchKernelGGL(frag_epilogue_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0,
-                           ctx->stream, (const float *)raw_frag, P, bank->M, fb->d_frag_first, bank->d_L,
-                           bank->d_cf, cp->d_utt_end, d_scores, d_ids, d_all);
+                           ctx->stream, (const float *)raw_frag, P, bank->M, fb->d_frag_ptr, fb->d_frag_idx,
+                           bank->d_L, bank->d_cf, cp->d_utt_end, d_scores, d_ids, d_all);
         TSR_HIP(hipGetLastError());
     }
     return TSR_OK;

@@ -22,18 +22,23 @@ constexpr int kThreads = 256;
 constexpr int KC = 16;   // parts per pass (accumulators per lane)
 constexpr int QC = 128;  // patch cells per LDS table chunk: QC*KC*16 B = 32 KiB
 
+// `row_bytes` is the byte stride between consecutive rows of X (X1*E for a plain map, the
+// resident stride Dp for a corpus).  With `utt_end` the rows are a concatenated frame stream:
+// a patch is live only if its P0 rows belong to one utterance.
 __global__ __launch_bounds__(kThreads) void code_parts_kernel(
-    const uint8_t *__restrict__ X, int X0, int X1, int E, int P0, int P1,
-    const double *__restrict__ tab /*[Q][K][2]*/, int K, unsigned threshold, int fast,
-    double *__restrict__ out /*[N0*N1][K+1] or null*/, int32_t *__restrict__ argmax /*or null*/)
+    const uint8_t *__restrict__ X, int X0, int X1, int E, int P0, int P1, int row_bytes,
+    const int32_t *__restrict__ utt_end, const double *__restrict__ tab /*[Q][K][2]*/, int K,
+    unsigned threshold, int fast, double *__restrict__ out /*[N0*N1][K+1] or null*/,
+    int32_t *__restrict__ argmax /*or null*/)
 {
     __shared__ __attribute__((aligned(16))) double lt[QC * KC * 2];
     const int N0 = X0 - P0 + 1, N1 = X1 - P1 + 1;
     const int Q = P0 * P1 * E;
     const int64_t loc = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    const bool live = loc < (int64_t)N0 * N1;
+    bool live = loc < (int64_t)N0 * N1;
     const int i0 = live ? (int)(loc / N1) : 0;
     const int j0 = live ? (int)(loc - (int64_t)i0 * N1) : 0;
+    if (live && utt_end) live = i0 + P0 <= utt_end[i0];
 
     unsigned count = 0;
     double slot0 = 0.0;       // code_parts_fast: sum_k (out[k+1] - 1), k ascending
@@ -59,7 +64,7 @@ __global__ __launch_bounds__(kThreads) void code_parts_kernel(
                     const int qq = qc0 + q;
                     const int z = qq % E, ij = qq / E;
                     const int j = ij % P1, i = ij / P1;
-                    const unsigned x = X[((int64_t)(i0 + i) * X1 + (j0 + j)) * E + z] ? 1u : 0u;
+                    const unsigned x = X[(int64_t)(i0 + i) * row_bytes + (j0 + j) * E + z] ? 1u : 0u;
                     if (kc0 == 0) count += x;
                     const double *row = lt + q * (KC * 2) + x;
 #pragma unroll
@@ -143,8 +148,8 @@ int tsr_launch_code_parts(tsr_ctx *ctx, const tsr_parts *parts, const uint8_t *d
     if (n_loc <= 0) return TSR_OK;
     hipLaunchKernelGGL(code_parts_kernel, dim3((unsigned)((n_loc + kThreads - 1) / kThreads)),
                        dim3(kThreads), 0, ctx->stream, d_X, (int)X0, (int)X1, (int)parts->E,
-                       (int)parts->P0, (int)parts->P1, parts->d_tab, (int)parts->K,
-                       (unsigned)threshold, fast, d_out, d_argmax);
+                       (int)parts->P0, (int)parts->P1, (int)(X1 * parts->E), (const int32_t *)nullptr,
+                       parts->d_tab, (int)parts->K, (unsigned)threshold, fast, d_out, d_argmax);
     TSR_HIP(hipGetLastError());
     return TSR_OK;
 }
@@ -170,6 +175,67 @@ int tsr_launch_spread_graph(tsr_ctx *ctx, uint8_t *d_X, int64_t n_loc, int64_t K
     if (n_loc <= 0 || K <= 0) return TSR_OK;
     hipLaunchKernelGGL(spread_graph_kernel, dim3((unsigned)((n_loc + kThreads - 1) / kThreads)),
                        dim3(kThreads), 0, ctx->stream, d_X, n_loc, (int)K, d_graph);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+
+// ---- corpus -> corpus: the front-end over a whole resident frame stream ---------------------
+namespace {
+// One thread per (output frame, output column): dilate the part-id map of the SOURCE stream over
+// the box clipped to the frame's own utterance, write the K bytes of the output row (resident
+// layout: row stride Dp_out, 0/1 bytes).  Rows must be zeroed beforehand.
+__global__ __launch_bounds__(kThreads) void spread_stream_kernel(
+    const int32_t *__restrict__ A /*[P_src][N1] part ids of the source stream*/, int N1, int r0, int r1,
+    int K, int g0, int g1, int O1, int64_t P_out, const int32_t *__restrict__ out_src_row /*[P_out]*/,
+    const int32_t *__restrict__ out_src_lo /*[P_out]*/, const int32_t *__restrict__ out_src_hi /*[P_out]*/,
+    const uint8_t *__restrict__ graph, int Dp_out, uint8_t *__restrict__ out)
+{
+    const int64_t o = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (o >= P_out * O1) return;
+    const int64_t pf = o / O1;
+    const int oj = (int)(o - pf * O1);
+    const int i = out_src_row[pf], j = oj * g1;
+    const int lo0 = max(i - r0, out_src_lo[pf]), hi0 = min(i + r0 + 1, out_src_hi[pf]);
+    const int lo1 = max(j - r1, 0), hi1 = min(j + r1 + 1, N1);
+    uint8_t *row = out + pf * Dp_out + (int64_t)oj * K;
+    for (int x0 = lo0; x0 < hi0; ++x0)
+        for (int x1 = lo1; x1 < hi1; ++x1) {
+            const int p = A[(int64_t)x0 * N1 + x1];
+            if (p > 0) row[p - 1] = 1;
+        }
+    if (graph)
+        for (int a = 0; a < K; ++a)
+            if (row[a] > 0)
+                for (int b = 0; b < K; ++b)
+                    if (graph[a * K + b]) row[b] = 1;
+}
+}  // namespace
+
+int tsr_launch_code_parts_stream(tsr_ctx *ctx, const tsr_parts *parts, const uint8_t *d_X, int64_t P,
+                                 int64_t X1, int Dp, const int32_t *d_utt_end, int threshold, int fast,
+                                 int32_t *d_argmax)
+{
+    const int64_t N1 = X1 - parts->P1 + 1;
+    const int64_t n_loc = (P - parts->P0 + 1) * N1;
+    if (n_loc <= 0) return TSR_OK;
+    hipLaunchKernelGGL(code_parts_kernel, dim3((unsigned)((n_loc + kThreads - 1) / kThreads)),
+                       dim3(kThreads), 0, ctx->stream, d_X, (int)P, (int)X1, (int)parts->E,
+                       (int)parts->P0, (int)parts->P1, Dp, d_utt_end, parts->d_tab, (int)parts->K,
+                       (unsigned)threshold, fast, (double *)nullptr, d_argmax);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+
+int tsr_launch_spread_stream(tsr_ctx *ctx, const int32_t *d_A, int64_t N1, int r0, int r1, int64_t K,
+                             int g0, int g1, int64_t O1, int64_t P_out, const int32_t *d_src_row,
+                             const int32_t *d_src_lo, const int32_t *d_src_hi, const uint8_t *d_graph,
+                             int Dp_out, uint8_t *d_out)
+{
+    const int64_t n = P_out * O1;
+    if (n <= 0) return TSR_OK;
+    hipLaunchKernelGGL(spread_stream_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads),
+                       0, ctx->stream, d_A, (int)N1, r0, r1, (int)K, g0, g1, (int)O1, P_out, d_src_row,
+                       d_src_lo, d_src_hi, d_graph, Dp_out, d_out);
     TSR_HIP(hipGetLastError());
     return TSR_OK;
 }

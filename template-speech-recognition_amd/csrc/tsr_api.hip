@@ -292,9 +292,12 @@ TSR_API int tsr_bank_info(const tsr_bank *b, int32_t *M, int64_t *D, int32_t *Lm
 }
 
 // ---- corpus ---------------------------------------------------------------------
+TSR_API int tsr_corpus_destroy(tsr_corpus *cp);
 
-TSR_API int tsr_corpus_create(tsr_ctx *ctx, const uint8_t *feats, const int64_t *frame_offsets,
-                              int64_t N, int64_t D, tsr_corpus **out)
+// Allocate a corpus (resident feature rows zero-initialised only in the slack, utterance tables
+// uploaded, result arrays allocated) without any feature data.
+int tsr_corpus_create_empty(tsr_ctx *ctx, const int64_t *frame_offsets, int64_t N, int64_t D,
+                            tsr_corpus **out)
 {
     TSR_REQUIRE(ctx && frame_offsets && out, "tsr_corpus_create: null pointer");
     *out = nullptr;
@@ -304,7 +307,6 @@ TSR_API int tsr_corpus_create(tsr_ctx *ctx, const uint8_t *feats, const int64_t 
         TSR_REQUIRE(frame_offsets[n + 1] >= frame_offsets[n], "tsr_corpus_create: frame_offsets not monotone at %lld", (long long)n);
     const int64_t P = frame_offsets[N];
     TSR_REQUIRE(P < (int64_t)1 << 31, "tsr_corpus_create: %lld frames exceed 2^31-1 per corpus", (long long)P);
-    TSR_REQUIRE(P == 0 || feats, "tsr_corpus_create: null feats");
     TSR_HIP(hipSetDevice(ctx->device));
     tsr_corpus *cp = new (std::nothrow) tsr_corpus;
     TSR_REQUIRE(cp, "tsr_corpus_create: out of host memory");
@@ -330,12 +332,6 @@ TSR_API int tsr_corpus_create(tsr_ctx *ctx, const uint8_t *feats, const int64_t 
         tsr_set_error("tsr_corpus_create: cannot allocate %zu bytes of device memory", body + slack);
         s = TSR_ERR_HIP;
     }
-    if (s == TSR_OK && P > 0) {
-        void *stage = nullptr;
-        s = tsr_scratch(ctx, SLOT_IN, (size_t)(P * D), &stage);
-        if (s == TSR_OK && hipMemcpyAsync(stage, feats, (size_t)(P * D), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
-        if (s == TSR_OK) s = tsr_launch_corpus_pack(ctx, (const uint8_t *)stage, P, (int)D, cp->Dp, cp->d_feats);
-    }
     if (s == TSR_OK) s = dev_upload(ctx, &cp->d_utt_beg, ub.data(), ub.size());
     if (s == TSR_OK) s = dev_upload(ctx, &cp->d_utt_end, ue.data(), ue.size(), 256 * sizeof(int32_t));  // zeroed slack: tiles read past P
     if (s == TSR_OK) s = dev_upload<float>(ctx, &cp->d_scores, nullptr, 0, (size_t)P * 4);
@@ -343,6 +339,34 @@ TSR_API int tsr_corpus_create(tsr_ctx *ctx, const uint8_t *feats, const int64_t 
     if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {
         tsr_set_error("tsr_corpus_create: upload failed");
         s = TSR_ERR_HIP;
+    }
+    if (s != TSR_OK) {
+        tsr_corpus_destroy(cp);
+        return s;
+    }
+    *out = cp;
+    return TSR_OK;
+}
+
+TSR_API int tsr_corpus_create(tsr_ctx *ctx, const uint8_t *feats, const int64_t *frame_offsets,
+                              int64_t N, int64_t D, tsr_corpus **out)
+{
+    TSR_REQUIRE(out, "tsr_corpus_create: null pointer");
+    tsr_corpus *cp = nullptr;
+    TSR_TRY(tsr_corpus_create_empty(ctx, frame_offsets, N, D, &cp));
+    const int64_t P = cp->P;
+    int s = TSR_OK;
+    if (P > 0) {
+        if (!feats) {
+            tsr_set_error("tsr_corpus_create: null feats");
+            s = TSR_ERR_INVALID;
+        }
+        void *stage = nullptr;
+        if (s == TSR_OK) s = tsr_scratch(ctx, SLOT_IN, (size_t)(P * D), &stage);
+        if (s == TSR_OK && hipMemcpyAsync(stage, feats, (size_t)(P * D), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
+        if (s == TSR_OK) s = tsr_launch_corpus_pack(ctx, (const uint8_t *)stage, P, (int)D, cp->Dp, cp->d_feats);
+        if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
+        if (s == TSR_ERR_HIP) tsr_set_error("tsr_corpus_create: upload failed");
     }
     if (s != TSR_OK) {
         tsr_corpus_destroy(cp);
@@ -711,6 +735,100 @@ TSR_API int tsr_part_features(tsr_ctx *ctx, const tsr_parts *parts, const uint8_
     TSR_HIP(hipStreamSynchronize(ctx->stream));
     if (argmax_out)
         for (size_t i = 0; i < am.size(); ++i) argmax_out[i] = am[i];
+    return TSR_OK;
+}
+
+// Edge-map corpus -> part-map corpus, entirely on the device (BASELINE config 3): for every
+// utterance code_parts[_fast] -> argmax -> spread(r0, r1) -> [graph] -> [::g0, ::g1], i.e.
+// get_train_data.py:2619-2628 / :183-191 applied to a whole resident frame stream.  The result is
+// a new corpus (D = O1*K per frame) that tsr_corpus_score consumes directly.
+TSR_API int tsr_corpus_part_features(tsr_ctx *ctx, const tsr_parts *parts, const tsr_corpus *edges,
+                                     int threshold, int fast, int r0, int r1, const uint8_t *graph,
+                                     int g0, int g1, tsr_corpus **out)
+{
+    TSR_REQUIRE(ctx && parts && edges && out, "tsr_corpus_part_features: null pointer");
+    *out = nullptr;
+    TSR_REQUIRE(r0 >= 0 && r1 >= 0 && g0 >= 1 && g1 >= 1, "tsr_corpus_part_features: bad radius/grid");
+    TSR_REQUIRE(edges->D % parts->E == 0, "tsr_corpus_part_features: corpus D=%lld is not a multiple of E=%lld", (long long)edges->D, (long long)parts->E);
+    const int64_t X1 = edges->D / parts->E, K = parts->K;
+    TSR_REQUIRE(X1 >= parts->P1, "tsr_corpus_part_features: %lld frequency bins < patch width %lld", (long long)X1, (long long)parts->P1);
+    TSR_HIP(hipSetDevice(ctx->device));
+    const int64_t N1 = X1 - parts->P1 + 1, O1 = (N1 + g1 - 1) / g1;
+    const int64_t N = edges->N;
+    // per-utterance geometry of the output stream
+    std::vector<int64_t> ooff((size_t)N + 1, 0);
+    for (int64_t n = 0; n < N; ++n) {
+        const int64_t T = edges->offsets[n + 1] - edges->offsets[n];
+        const int64_t N0 = T >= parts->P0 ? T - parts->P0 + 1 : 0;
+        ooff[n + 1] = ooff[n] + (N0 + g0 - 1) / g0;
+    }
+    const int64_t P_out = ooff[N];
+    std::vector<int32_t> src_row((size_t)P_out), src_lo((size_t)P_out), src_hi((size_t)P_out);
+    for (int64_t n = 0; n < N; ++n) {
+        const int64_t beg = edges->offsets[n], T = edges->offsets[n + 1] - beg;
+        const int64_t N0 = T >= parts->P0 ? T - parts->P0 + 1 : 0;
+        for (int64_t q = ooff[n]; q < ooff[n + 1]; ++q) {
+            src_row[(size_t)q] = (int32_t)(beg + (q - ooff[n]) * g0);
+            src_lo[(size_t)q] = (int32_t)beg;
+            src_hi[(size_t)q] = (int32_t)(beg + N0);
+        }
+    }
+    // the output corpus object (features are produced on the device, not uploaded)
+    tsr_corpus *cp = nullptr;
+    {
+        std::vector<uint8_t> none;
+        TSR_TRY(tsr_corpus_create_empty(ctx, ooff.data(), N, O1 * K, &cp));
+    }
+    void *dA = nullptr, *dRow = nullptr, *dG = nullptr;
+    int s = tsr_scratch(ctx, SLOT_AUX, (size_t)std::max<int64_t>(edges->P * N1, 1) * 4, &dA);
+    if (s == TSR_OK) s = tsr_scratch(ctx, SLOT_W, (size_t)std::max<int64_t>(P_out, 1) * 12, &dRow);
+    int32_t *d_src_row = (int32_t *)dRow, *d_src_lo = d_src_row + P_out, *d_src_hi = d_src_lo + P_out;
+    if (s == TSR_OK && P_out > 0) {
+        if (hipMemcpyAsync(d_src_row, src_row.data(), (size_t)P_out * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(d_src_lo, src_lo.data(), (size_t)P_out * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(d_src_hi, src_hi.data(), (size_t)P_out * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+            s = TSR_ERR_HIP;
+    }
+    if (s == TSR_OK && graph) {
+        s = tsr_scratch(ctx, SLOT_AUX2, (size_t)(K * K), &dG);
+        if (s == TSR_OK && hipMemcpyAsync(dG, graph, (size_t)(K * K), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
+    }
+    if (s == TSR_OK && edges->P > 0)
+        s = tsr_launch_code_parts_stream(ctx, parts, edges->d_feats, edges->P, X1, edges->Dp, edges->d_utt_end,
+                                         threshold, fast, (int32_t *)dA);
+    if (s == TSR_OK && P_out > 0) {
+        if (hipMemsetAsync(cp->d_feats, 0, (size_t)P_out * cp->Dp, ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
+        if (s == TSR_OK)
+            s = tsr_launch_spread_stream(ctx, (const int32_t *)dA, N1, r0, r1, K, g0, g1, O1, P_out, d_src_row,
+                                         d_src_lo, d_src_hi, (const uint8_t *)dG, cp->Dp, cp->d_feats);
+    }
+    if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = TSR_ERR_HIP;  // host staging dies here
+    if (s != TSR_OK) {
+        if (s == TSR_ERR_HIP) tsr_set_error("tsr_corpus_part_features: device copy/launch failed");
+        tsr_corpus_destroy(cp);
+        return s;
+    }
+    *out = cp;
+    return TSR_OK;
+}
+
+TSR_API int tsr_corpus_download_feats(tsr_ctx *ctx, const tsr_corpus *cp, uint8_t *feats)
+{
+    TSR_REQUIRE(ctx && cp && (feats || cp->P == 0), "tsr_corpus_download_feats: null pointer");
+    TSR_HIP(hipSetDevice(ctx->device));
+    if (cp->P)
+        TSR_HIP(hipMemcpy2DAsync(feats, (size_t)cp->D, cp->d_feats, (size_t)cp->Dp, (size_t)cp->D, (size_t)cp->P,
+                                 hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    return TSR_OK;
+}
+
+TSR_API int tsr_corpus_shape(const tsr_corpus *cp, int64_t *N, int64_t *D, int64_t *frame_offsets)
+{
+    TSR_REQUIRE(cp, "tsr_corpus_shape: null corpus");
+    if (N) *N = cp->N;
+    if (D) *D = cp->D;
+    if (frame_offsets) memcpy(frame_offsets, cp->offsets.data(), (size_t)(cp->N + 1) * sizeof(int64_t));
     return TSR_OK;
 }
 

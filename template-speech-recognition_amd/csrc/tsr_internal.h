@@ -58,6 +58,8 @@ struct tsr_ctx {
 };
 
 int tsr_scratch(tsr_ctx *ctx, int slot, size_t bytes, void **out);
+int tsr_corpus_create_empty(tsr_ctx *ctx, const int64_t *frame_offsets, int64_t N, int64_t D,
+                            struct tsr_corpus **out);
 
 // ---- bank ---------------------------------------------------------------------
 // Exact path: templates in groups of TSR_MG; group g holds, for every (tau, d4),
@@ -143,3 +145,10 @@ int tsr_launch_spread(tsr_ctx *ctx, const int32_t *d_A, int64_t X0, int64_t X1, 
                       int64_t K, int g0, int g1, const uint8_t *d_graph, uint8_t *d_out);
 int tsr_launch_spread_graph(tsr_ctx *ctx, uint8_t *d_X, int64_t n_loc, int64_t K,
                             const uint8_t *d_graph);
+int tsr_launch_code_parts_stream(tsr_ctx *ctx, const tsr_parts *parts, const uint8_t *d_X, int64_t P,
+                                 int64_t X1, int Dp, const int32_t *d_utt_end, int threshold, int fast,
+                                 int32_t *d_argmax);
+int tsr_launch_spread_stream(tsr_ctx *ctx, const int32_t *d_A, int64_t N1, int r0, int r1, int64_t K,
+                             int g0, int g1, int64_t O1, int64_t P_out, const int32_t *d_src_row,
+                             const int32_t *d_src_lo, const int32_t *d_src_hi, const uint8_t *d_graph,
+                             int Dp_out, uint8_t *d_out);

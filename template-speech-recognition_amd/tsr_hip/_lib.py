@@ -45,6 +45,9 @@ SIGNATURES = {
     "tsr_parts_create": [_p, _p, _p, _i64, _i64, _i64, _i64, _pp],
     "tsr_parts_destroy": [_p],
     "tsr_part_features": [_p, _p, _p, _i64, _i64, _int, _int, _int, _int, _p, _int, _int, _p, _p],
+    "tsr_corpus_part_features": [_p, _p, _p, _int, _int, _int, _int, _p, _int, _int, _pp],
+    "tsr_corpus_download_feats": [_p, _p, _p],
+    "tsr_corpus_shape": [_p, C.POINTER(_i64), C.POINTER(_i64), _p],
     "tsr_dist_unique_id": [C.c_char_p],
     "tsr_dist_init": [_p, C.c_char_p, _int, _int],
     "tsr_dist_finalize": [_p],

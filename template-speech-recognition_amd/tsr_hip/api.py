@@ -169,6 +169,7 @@ class Corpus:
         if feats.size != P * D:
             raise ValueError("feats has %d bytes, expected %d frames x D=%d" % (feats.size, P, D))
         self.P, self.D, self.N = P, int(D), len(offs) - 1
+        self.offsets = offs
         h = C.c_void_p()
         check(lib().tsr_corpus_create(self.ctx._h, ptr(feats), ptr(offs), self.N, self.D, C.byref(h)))
         self._h = h
@@ -183,6 +184,35 @@ class Corpus:
             self.close()
         except Exception:
             pass
+
+    @classmethod
+    def _adopt(cls, handle, ctx):
+        """Wrap a tsr_corpus* produced on the device (no upload)."""
+        self = cls.__new__(cls)
+        self.ctx, self._h = ctx, handle
+        n, d = C.c_int64(), C.c_int64()
+        check(lib().tsr_corpus_shape(handle, C.byref(n), C.byref(d), None))
+        self.N, self.D = int(n.value), int(d.value)
+        self.offsets = np.empty(self.N + 1, np.int64)
+        check(lib().tsr_corpus_shape(handle, None, None, ptr(self.offsets)))
+        self.P = int(self.offsets[-1])
+        return self
+
+    def part_features(self, parts, threshold, spread=(0, 0), graph=None, grid=(1, 1), fast=False):
+        """Edge-map corpus -> part-map corpus on the device (code_parts -> argmax -> spread ->
+        [graph] -> [::g0, ::g1] per utterance; get_train_data.py:2619-2628 / :183-191)."""
+        g = None if graph is None else np.ascontiguousarray(graph, dtype=np.uint8)
+        h = C.c_void_p()
+        check(lib().tsr_corpus_part_features(self.ctx._h, parts._h, self._h, int(threshold), int(bool(fast)),
+                                             int(spread[0]), int(spread[1]), ptr(g), int(grid[0]),
+                                             int(grid[1]), C.byref(h)))
+        return Corpus._adopt(h, self.ctx)
+
+    def download_feats(self):
+        """The resident feature bytes as u8 [sum T, D] (0/1)."""
+        out = np.empty((self.P, self.D), np.uint8)
+        check(lib().tsr_corpus_download_feats(self.ctx._h, self._h, ptr(out)))
+        return out
 
     def score(self, bank, flags=TSR_EXACT):
         """Enqueue one scoring pass on the ctx stream (asynchronous)."""

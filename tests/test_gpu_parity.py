@@ -267,3 +267,50 @@ def test_config2_full_size_properties(mods, oracle):
     assert np.all(tail == cf.max()) and np.all(a.reshape(1000, 200)[:, 169:] == int(np.argmax(cf)))
     s2, a2 = bank.score(feats[offs[500]:], offs[500:] - offs[500])    # second half alone
     assert np.array_equal(s2, s[offs[500]:]) and np.array_equal(a2, a[offs[500]:])
+
+
+# ---- device-resident front-end chain: edge corpus -> part corpus -> scores (config 3) ----------
+@pytest.mark.parametrize("variant", ["parts", "parts_graph", "waliji"])
+def test_corpus_part_features_chain(mods, oracle, variant):
+    tsr_hip = mods[3]
+    from tsr_hip import synth
+    rng = np.random.default_rng(77)
+    F, K = 14, 7
+    Ts = [40, 3, 26, 5, 31]  # includes utterances shorter than / equal to the 5-frame patch
+    q = rng.uniform(0.05, 0.45, size=(F, 8))
+    edges = [synth.features(rng, T, q) for T in Ts]
+    lp, lip = synth.parts(rng, K)
+    graph = (rng.random((K, K)) < 0.1).astype(np.uint8) if variant == "parts_graph" else None
+    if variant == "waliji":
+        thr, spread, grid, fast = 10, (5, 5), (5, 5), True
+    else:
+        thr, spread, grid, fast = 12, (2, 2), (1, 1), False
+    offs = np.concatenate(([0], np.cumsum(Ts)))
+    corpus = tsr_hip.Corpus(np.concatenate(edges).reshape(int(offs[-1]), -1), offs)
+    parts = tsr_hip.Parts(lp, lip)
+    pc = corpus.part_features(parts, thr, spread=spread, graph=graph, grid=grid, fast=fast)
+    want = []
+    for E in edges:
+        if E.shape[0] < 5:
+            want.append(np.zeros((0, (F - 4 + grid[1] - 1) // grid[1], K), np.uint8))
+            continue
+        cp_fn = oracle.code_parts_fast if fast else oracle.code_parts
+        am = oracle.argmax_last(cp_fn(E, lp, lip, thr))
+        sp = oracle.spread_patches(am, spread[0], spread[1], K)
+        if graph is not None:
+            oracle.spread_graph_patches(sp, graph)
+        want.append(np.ascontiguousarray(sp[::grid[0], ::grid[1]]))
+    assert pc.offsets.tolist() == np.concatenate(([0], np.cumsum([w.shape[0] for w in want]))).tolist()
+    got = pc.download_feats()
+    assert np.array_equal(got, np.concatenate([w.reshape(w.shape[0], pc.D) for w in want]))
+    # and straight on into the scorer, both precisions
+    D2 = pc.D
+    bank_cs = synth.bank(rng, synth.background(rng, (D2,)), [3, 2, 4] if variant == "waliji" else [9, 12, 6])
+    bank = tsr_hip.Bank(bank_cs)
+    so, ao = oracle.score_corpus(got, pc.offsets, bank_cs)
+    pc.score(bank, tsr_hip.TSR_EXACT)
+    s, a = pc.download()
+    assert np.array_equal(s, so) and np.array_equal(a, ao)
+    pc.score(bank, tsr_hip.TSR_FAST)
+    s, a = pc.download()
+    assert rel_err(s, so) <= TOL

@@ -1,0 +1,24 @@
+"""Time BASELINE config 3 on the device: edge corpus -> code_parts/argmax/spread -> D=2050 bank."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "template-speech-recognition_amd"))
+import numpy as np
+import tsr_hip
+from tsr_hip import synth
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+rng = np.random.default_rng(3)
+q = synth.background(rng, (45, 8))
+feats = (rng.random((N * 200, 45, 8)) < q).astype(np.uint8)
+offs = np.arange(N + 1, dtype=np.int64) * 200
+lp, lip = synth.parts(rng, 50)
+ctx = tsr_hip.Context(0)
+corpus = tsr_hip.Corpus(feats.reshape(N * 200, -1), offs, ctx=ctx)
+parts = tsr_hip.Parts(lp, lip, ctx=ctx)
+bank = tsr_hip.Bank(synth.bank(rng, synth.background(rng, (41, 50)), [32] * 8), ctx=ctx)
+for rep in range(3):
+    ctx.sync(); t0 = time.perf_counter()
+    pc = corpus.part_features(parts, 12, spread=(2, 2))
+    ctx.sync(); t1 = time.perf_counter()
+    pc.score(bank, tsr_hip.TSR_FAST); ctx.sync(); t2 = time.perf_counter()
+    pc.score(bank, tsr_hip.TSR_FAST); ctx.sync(); t3 = time.perf_counter()
+    print("N=%d: front-end %.2f ms, bank first %.2f ms, bank again %.3f ms  (part map density %.3f)"
+          % (N, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, 0.0 if rep else float(pc.download_feats().mean())))
