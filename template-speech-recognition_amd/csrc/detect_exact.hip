@@ -18,33 +18,25 @@ namespace {
 
 constexpr int kThreads = 256;
 
-// One block = TB consecutive frame positions x (256/TB) template groups.
-// LDS holds rows [p0 + tau0, p0 + tau0 + TB + TC - 1) of the feature map (0/1
-// bytes, see corpus_pack_kernel), SD dwords per row (SD odd => conflict-free
-// stride across lanes).
+// One block = TB consecutive frame positions of the stream x one group of TSR_MG templates.
+// The frames are bit-packed on the way into LDS (one dword = 32 features), which shrinks the
+// tile 8x against the resident bytes: ~15 KiB for TB = 256 at D = 360, so 8 waves fit per SIMD
+// and the scalar weight loads (one wave-uniform 32-byte line per feature: 8 templates) are
+// hidden by the other waves.  Per feature: v_bfe + v_cvt build x in {0.0, 1.0}, then 8 v_fmac.
+// LDS rows are an odd number of dwords apart (conflict-free across lanes).
 template <int TB>
-__global__ __launch_bounds__(kThreads) void exact_bank_kernel(
-    const uint8_t *__restrict__ X, int64_t P, int Dp, int Dq, int SD, int TC,
-    const float *__restrict__ Wx, const int64_t *__restrict__ gx_off,
-    const int32_t *__restrict__ gx_L, int n_groups, int M, float *__restrict__ raw)
+__global__ __launch_bounds__(TB) void exact_bank_kernel(
+    const uint8_t *__restrict__ X, int64_t P, int D, int Dp, int WR /*dwords of bits per row*/,
+    int SD /*LDS row stride, odd*/, int TC, const float *__restrict__ Wx,
+    const int64_t *__restrict__ gx_off, const int32_t *__restrict__ gx_L, int M,
+    float *__restrict__ raw)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    constexpr int GPB = kThreads / TB;  // template groups per block
     const int tid = threadIdx.x;
-    const int pos = tid % TB;
-    // wave-uniform (TB is a multiple of 64); readfirstlane makes that provable so that
-    // the weight lines below are fetched with scalar loads into SGPRs
-    const int g = blockIdx.y * GPB + __builtin_amdgcn_readfirstlane(tid / TB);
+    const int g = blockIdx.y;
     const int64_t p0 = (int64_t)blockIdx.x * TB;
-    const bool active = g < n_groups;
-    const int Lg = active ? gx_L[g] : 0;
-    const float *__restrict__ Wg = Wx + (active ? gx_off[g] : 0);
-
-    int Lblk = 0;  // longest template over the groups of this block
-    for (int k = 0; k < GPB; ++k) {
-        int gg = blockIdx.y * GPB + k;
-        if (gg < n_groups) Lblk = max(Lblk, gx_L[gg]);
-    }
+    const int Lg = gx_L[g];
+    const float *__restrict__ Wg = Wx + gx_off[g];
 
     float acc[TSR_MG];
 #pragma unroll
@@ -53,39 +45,44 @@ __global__ __launch_bounds__(kThreads) void exact_bank_kernel(
     const int rows = TB + TC - 1;
     const uint32_t *__restrict__ X4 = reinterpret_cast<const uint32_t *>(X);
     const int Dp4 = Dp >> 2;
-    for (int tau0 = 0; tau0 < Lblk; tau0 += TC) {
+    for (int tau0 = 0; tau0 < Lg; tau0 += TC) {
         __syncthreads();
-        // ---- stage rows [p0+tau0, p0+tau0+rows): the corpus holds 0/1 bytes in rows of
-        //      Dp bytes (Dp % 16 == 0, zero padded), so whole dwords can be copied
-        for (int idx = tid; idx < rows * SD; idx += kThreads) {
-            const int r = idx / SD, i = idx - r * SD;
+        // ---- stage rows [p0+tau0, p0+tau0+rows): 32 resident 0/1 bytes -> one dword of bits.
+        //      (x * 0x01020408) >> 24 gathers the low bits of 4 bytes into a nibble.
+        for (int idx = tid; idx < rows * WR; idx += TB) {
+            const int r = idx / WR, w = idx - r * WR;
             const int64_t p = p0 + tau0 + r;
-            lds[idx] = (p < P && i < Dq) ? X4[p * Dp4 + i] : 0u;
+            uint32_t bits = 0;
+            if (p < P) {
+                const uint32_t *src = X4 + p * Dp4 + w * 8;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const uint32_t x = (w * 8 + q < Dp4) ? src[q] : 0u;  // rows are zero padded up to Dp
+                    bits |= ((x * 0x01020408u) >> 24 & 0xfu) << (4 * q);
+                }
+            }
+            lds[r * SD + w] = bits;
         }
         __syncthreads();
-        // ---- accumulate taps tau0 .. min(tau0+TC, Lg) in reference order ---------
+        // ---- accumulate taps tau0 .. min(tau0+TC, Lg) in reference order: tau -> feature ----
         const int tau1 = min(tau0 + TC, Lg);
         for (int tau = tau0; tau < tau1; ++tau) {
-            const uint32_t *xr = lds + (pos + (tau - tau0)) * SD;
-            const float *__restrict__ w = Wg + (int64_t)tau * Dq * (TSR_MG * 4);
-#pragma unroll 2
-            for (int i = 0; i < Dq; ++i) {
-                const uint32_t x = xr[i];
-                const float x0 = (float)(x & 0xffu), x1 = (float)((x >> 8) & 0xffu),
-                            x2 = (float)((x >> 16) & 0xffu), x3 = (float)(x >> 24);
-                const float *__restrict__ wi = w + i * (TSR_MG * 4);
+            const uint32_t *xr = lds + (tid + (tau - tau0)) * SD;
+            const float *__restrict__ w = Wg + (int64_t)tau * WR * 32 * TSR_MG;
+            for (int i = 0; i < WR; ++i) {
+                const uint32_t bits = xr[i];
+                const float *__restrict__ wi = w + i * (32 * TSR_MG);
 #pragma unroll
-                for (int m = 0; m < TSR_MG; ++m) {
-                    acc[m] = __builtin_fmaf(x0, wi[4 * m + 0], acc[m]);
-                    acc[m] = __builtin_fmaf(x1, wi[4 * m + 1], acc[m]);
-                    acc[m] = __builtin_fmaf(x2, wi[4 * m + 2], acc[m]);
-                    acc[m] = __builtin_fmaf(x3, wi[4 * m + 3], acc[m]);
+                for (int j = 0; j < 32; ++j) {
+                    const float x = (float)((bits >> j) & 1u);
+#pragma unroll
+                    for (int m = 0; m < TSR_MG; ++m) acc[m] = __builtin_fmaf(x, wi[j * TSR_MG + m], acc[m]);
                 }
             }
         }
     }
-    const int64_t p = p0 + pos;
-    if (active && p < P) {
+    const int64_t p = p0 + tid;
+    if (p < P) {
 #pragma unroll
         for (int m = 0; m < TSR_MG; ++m) {
             const int mm = g * TSR_MG + m;
@@ -97,7 +94,7 @@ __global__ __launch_bounds__(kThreads) void exact_bank_kernel(
 // Fallback for feature rows too wide for the LDS tile: same order, rows read
 // straight from global memory (L1/L2 absorb the window overlap).
 __global__ __launch_bounds__(kThreads) void exact_bank_direct_kernel(
-    const uint8_t *__restrict__ X, int64_t P, int D, int Dp, int Dq,
+    const uint8_t *__restrict__ X, int64_t P, int D, int Dp, int WR,
     const float *__restrict__ Wx, const int64_t *__restrict__ gx_off,
     const int32_t *__restrict__ gx_L, int M, float *__restrict__ raw)
 {
@@ -110,12 +107,12 @@ __global__ __launch_bounds__(kThreads) void exact_bank_direct_kernel(
     for (int m = 0; m < TSR_MG; ++m) acc[m] = 0.0f;
     for (int tau = 0; tau < Lg; ++tau) {
         const int64_t row = p + tau;
-        const float *__restrict__ w = Wg + (int64_t)tau * Dq * (TSR_MG * 4);
+        const float *__restrict__ w = Wg + (int64_t)tau * WR * 32 * TSR_MG;
         for (int d = 0; d < D; ++d) {
             const float x = (row < P && X[row * Dp + d]) ? 1.0f : 0.0f;
-            const float *__restrict__ wi = w + (d >> 2) * (TSR_MG * 4) + (d & 3);
+            const float *__restrict__ wi = w + (int64_t)d * TSR_MG;
 #pragma unroll
-            for (int m = 0; m < TSR_MG; ++m) acc[m] = __builtin_fmaf(x, wi[4 * m], acc[m]);
+            for (int m = 0; m < TSR_MG; ++m) acc[m] = __builtin_fmaf(x, wi[m], acc[m]);
         }
     }
     if (p < P) {
@@ -200,44 +197,24 @@ int tsr_launch_exact_bank(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *d_f
                           int Dp, float *d_raw)
 {
     if (P == 0) return TSR_OK;
-    const int Dq = bank->Dq;
-    const int SD = Dq | 1;
+    const int WR = bank->Dq;  // dwords of feature bits per row
+    const int SD = WR | 1;
     const int Lmax = bank->Lmax;
-    const int64_t *d_gx_off = bank->d_gx_off;
-    const int32_t *d_gx_L = bank->d_gx_L;
     const size_t row_bytes = (size_t)SD * 4;
-    const size_t pref = 64 * 1024, cap = 150 * 1024;
-    int TB = 0, TC = 0;
-    if (pref / row_bytes >= 128 + 1) {
-        TB = 128;
-        TC = (int)std::min<size_t>(Lmax, pref / row_bytes - 127);
-    } else if (cap / row_bytes >= 64 + 1) {
-        TB = 64;
-        TC = (int)std::min<size_t>(Lmax, cap / row_bytes - 63);
-    }
-    if (TB == 0) {
+    constexpr int TB = 256;
+    const size_t budget = 64 * 1024;  // keep several blocks per CU resident
+    if (budget / row_bytes < (size_t)TB + 1) {  // absurdly wide rows: stream from global memory
         dim3 grid((unsigned)((P + kThreads - 1) / kThreads), bank->n_groups);
         hipLaunchKernelGGL(exact_bank_direct_kernel, grid, dim3(kThreads), 0, ctx->stream, d_feats, P,
-                           (int)bank->D, Dp, Dq, bank->d_Wx, d_gx_off, d_gx_L, bank->M, d_raw);
+                           (int)bank->D, Dp, WR, bank->d_Wx, bank->d_gx_off, bank->d_gx_L, bank->M, d_raw);
         TSR_HIP(hipGetLastError());
         return TSR_OK;
     }
+    const int TC = (int)std::min<size_t>(Lmax, budget / row_bytes - (TB - 1));
     const size_t lds = (size_t)(TB + TC - 1) * row_bytes;
-    const int GPB = kThreads / TB;
-    dim3 grid((unsigned)((P + TB - 1) / TB), (bank->n_groups + GPB - 1) / GPB);
-    if (TB == 128) {
-        TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(exact_bank_kernel<128>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(exact_bank_kernel<128>, grid, dim3(kThreads), lds, ctx->stream, d_feats, P,
-                           Dp, Dq, SD, TC, bank->d_Wx, d_gx_off, d_gx_L, bank->n_groups,
-                           bank->M, d_raw);
-    } else {
-        TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(exact_bank_kernel<64>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(exact_bank_kernel<64>, grid, dim3(kThreads), lds, ctx->stream, d_feats, P,
-                           Dp, Dq, SD, TC, bank->d_Wx, d_gx_off, d_gx_L, bank->n_groups,
-                           bank->M, d_raw);
-    }
+    dim3 grid((unsigned)((P + TB - 1) / TB), bank->n_groups);
+    hipLaunchKernelGGL(exact_bank_kernel<TB>, grid, dim3(TB), lds, ctx->stream, d_feats, P, (int)bank->D,
+                       Dp, WR, SD, TC, bank->d_Wx, bank->d_gx_off, bank->d_gx_L, bank->M, d_raw);
     TSR_HIP(hipGetLastError());
     return TSR_OK;
 }

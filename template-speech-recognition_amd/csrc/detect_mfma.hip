@@ -711,41 +711,51 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int NL)
     return s;
 }
 
-// Partition the frame stream into `nseg` segments of near-equal length, cutting at
-// utterance boundaries when one is close (no halo needed there: windows never span
-// utterances) and inside an utterance otherwise (the segment then also reads the
-// Lmax-1 frames that its last windows overhang).
+// Partition the frame stream into `nseg` segments (one per workgroup of a column group).  A cut
+// inside an utterance makes the segment also read the Lmax-1 frames its last windows overhang;
+// a cut at an utterance boundary needs no halo (windows never span utterances).  The launch
+// lasts as long as its longest segment, so cuts start uniform and are moved to a boundary only
+// when that does not lengthen the longest segment.
 static int build_plan(tsr_ctx *ctx, tsr_corpus *cp, int nseg, int Lmax)
 {
     const int key = nseg * 65536 + Lmax;
     if (cp->d_plan && cp->plan_key == key) return TSR_OK;
     const int64_t P = cp->P;
     std::vector<int32_t> plan((size_t)3 * nseg);
-    const double target = (double)P / nseg;
-    std::vector<int64_t> cuts(nseg + 1, 0);
-    cuts[nseg] = P;
     const std::vector<int64_t> &off = cp->offsets;
+    auto is_boundary = [&](int64_t p) { return std::binary_search(off.begin(), off.end(), p); };
+    auto tiles_of = [&](int64_t o0, int64_t o1) -> int64_t {  // row tiles a segment costs
+        if (o1 <= o0) return 0;
+        const int64_t rows = is_boundary(o1) ? o1 - o0 : std::min<int64_t>(P, o1 + Lmax - 1) - o0;
+        return (rows + 31) / 32;
+    };
+    // 1) uniform cuts: the launch lasts as long as its longest segment (in 32-row tiles)
+    std::vector<int64_t> cuts(nseg + 1, 0);
+    for (int i = 1; i < nseg; ++i) cuts[i] = (int64_t)llrint((double)P * i / nseg);
+    cuts[nseg] = P;
+    int64_t tmax = 0;
+    for (int i = 0; i < nseg; ++i) tmax = std::max(tmax, tiles_of(cuts[i], cuts[i + 1]));
+    // 2) snap a cut to a nearby utterance boundary (no halo rows needed there) whenever that
+    //    keeps both neighbouring segments within the uniform plan's longest segment
     for (int i = 1; i < nseg; ++i) {
-        const int64_t ideal = (int64_t)llrint(i * target);
-        auto it = std::lower_bound(off.begin(), off.end(), ideal);
+        auto it = std::lower_bound(off.begin(), off.end(), cuts[i]);
+        int64_t cand[2] = {-1, -1};
+        if (it != off.end()) cand[0] = *it;
+        if (it != off.begin()) cand[1] = *(it - 1);
         int64_t best = -1;
-        if (it != off.end()) best = *it;
-        if (it != off.begin()) {
-            const int64_t lo = *(it - 1);
-            if (best < 0 || ideal - lo < best - ideal) best = lo;
+        for (int64_t c : cand) {
+            if (c < 0 || c <= cuts[i - 1] || c >= cuts[i + 1]) continue;
+            if (tiles_of(cuts[i - 1], c) > tmax || tiles_of(c, cuts[i + 1]) > tmax) continue;
+            if (best < 0 || llabs(c - cuts[i]) < llabs(best - cuts[i])) best = c;
         }
-        // snap to an utterance boundary only when it is within ~1.5 tiles of the ideal cut:
-        // a halo costs one tile, an unbalanced segment costs the whole launch its excess
-        const bool near = best >= 0 && llabs(best - ideal) <= 48;
-        int64_t cut = near ? best : (ideal / 32) * 32;
-        cuts[i] = std::min<int64_t>(std::max(cut, cuts[i - 1]), P);
+        if (best >= 0) cuts[i] = best;
     }
     for (int i = 0; i < nseg; ++i) {
         const int64_t o0 = cuts[i], o1 = cuts[i + 1];
-        const bool boundary = std::binary_search(off.begin(), off.end(), o1);
         plan[(size_t)i] = (int32_t)o0;
         plan[(size_t)nseg + i] = (int32_t)o1;
-        plan[(size_t)2 * nseg + i] = (int32_t)((o1 > o0 && !boundary) ? std::min<int64_t>(P, o1 + Lmax - 1) : o1);
+        plan[(size_t)2 * nseg + i] =
+            (int32_t)((o1 > o0 && !is_boundary(o1)) ? std::min<int64_t>(P, o1 + Lmax - 1) : o1);
     }
     if (cp->d_plan) {
         TSR_HIP(hipStreamSynchronize(ctx->stream));

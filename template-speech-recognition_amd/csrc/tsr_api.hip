@@ -175,11 +175,11 @@ enum { SLOT_RAW = 0, SLOT_IN = 1, SLOT_W = 2, SLOT_OUT = 3, SLOT_AUX = 4, SLOT_A
 // ---- bank ----------------------------------------------------------------------
 static int bank_build_exact(tsr_ctx *ctx, tsr_bank *b)
 {
-    // Wx[g][tau][d4][m][j]  (see tsr_internal.h)
+    // Wx[g][tau][d][m]  (see tsr_internal.h)
     const int M = b->M;
     const int64_t D = b->D;
-    const int Dq = (int)((D + 3) / 4);
-    b->Dq = Dq;
+    const int WR = (int)((D + 31) / 32);
+    b->Dq = WR;
     b->n_groups = (M + TSR_MG - 1) / TSR_MG;
     b->gx_off.assign(b->n_groups, 0);
     b->gx_L.assign(b->n_groups, 0);
@@ -189,7 +189,7 @@ static int bank_build_exact(tsr_ctx *ctx, tsr_bank *b)
         for (int m = g * TSR_MG; m < std::min(M, (g + 1) * TSR_MG); ++m) Lg = std::max(Lg, b->L[m]);
         b->gx_off[g] = total;
         b->gx_L[g] = Lg;
-        total += (int64_t)Lg * Dq * TSR_MG * 4;
+        total += (int64_t)Lg * WR * 32 * TSR_MG;
     }
     std::vector<float> Wx((size_t)total, 0.0f);
     int64_t woff = 0;
@@ -199,7 +199,7 @@ static int bank_build_exact(tsr_ctx *ctx, tsr_bank *b)
         const float *src = b->W_cat.data() + woff;
         for (int tau = 0; tau < b->L[m]; ++tau)
             for (int64_t d = 0; d < D; ++d)
-                dst[(((int64_t)tau * Dq + d / 4) * TSR_MG + mi) * 4 + (d & 3)] = src[(int64_t)tau * D + d];
+                dst[((int64_t)tau * WR * 32 + d) * TSR_MG + mi] = src[(int64_t)tau * D + d];
         woff += (int64_t)b->L[m] * D;
     }
     dev_free(b->d_Wx);

@@ -62,11 +62,11 @@ int tsr_corpus_create_empty(tsr_ctx *ctx, const int64_t *frame_offsets, int64_t 
                             struct tsr_corpus **out);
 
 // ---- bank ---------------------------------------------------------------------
-// Exact path: templates in groups of TSR_MG; group g holds, for every (tau, d4),
-// TSR_MG x 4 floats  Wx[g][tau][d4][m][j] = W_{g*MG+m}[tau][4*d4+j]  (zero padded
-// in tau beyond L_m, in d beyond D and for m beyond M), so that one wave-uniform
-// 16-float line feeds 4 templates x 4 consecutive features.
-#define TSR_MG 4
+// Exact path: templates in groups of TSR_MG; group g holds, for every (tau, d),
+// TSR_MG floats  Wx[g][tau][d][m] = W_{g*MG+m}[tau][d]  (zero padded in tau beyond
+// L_m, in d up to a multiple of 32 and for m beyond M), so that one wave-uniform
+// 32-byte line feeds 8 templates for one feature.
+#define TSR_MG 8
 
 // Fast (MFMA) path: see detect_mfma.hip for the limb layout.
 struct tsr_bank {
@@ -81,7 +81,7 @@ struct tsr_bank {
     std::vector<float> W_cat; // host copy (needed to rebuild device forms after a broadcast)
     // device, exact path
     int32_t n_groups = 0;
-    int32_t Dq = 0;                  // ceil(D/4)
+    int32_t Dq = 0;                  // ceil(D/32): dwords of feature bits per frame
     float *d_Wx = nullptr;           // all groups back to back
     std::vector<int64_t> gx_off;     // float offset of group g in d_Wx
     std::vector<int32_t> gx_L;       // max L in group g
