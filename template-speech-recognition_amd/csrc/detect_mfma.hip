@@ -412,6 +412,126 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
         x_cur = x_nxt;
     };
 
+    // ---- steady-state iteration: the same work as tile_iter for the common case -- interior
+    //      tile, DMA of tile t+2 due, finishing phases A/B (tile t-lag) and C (tile t-lag-1) all
+    //      active, at most 16 slots -- with every loop-invariant hoisted: this lane's slot
+    //      metadata in registers, LDS byte addresses precomputed, no predication.  A wave issues
+    //      about one instruction per four cycles, so the instruction COUNT of this loop is what
+    //      decides whether the matrix pipe stays fed.
+    typedef __attribute__((address_space(3))) int lds_i32;
+    typedef __attribute__((address_space(3))) ring_t lds_ring;
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+    typedef __attribute__((address_space(3))) const i32x4 lds_frag;
+    const int lane31 = lane & 31;
+    const int my_s = wave + 8 * half;  // the slot this lane finishes
+    const bool s_ok = my_s < nslots;
+    const SlotMeta my_sm = a.slots[cg * kMaxSlots + min(my_s, kMaxSlots - 1)];
+    const unsigned st_fin_row = lds_addr(ring + (s_ok ? my_s : nslots) * rstride + lane31);
+    const unsigned st_uend = lds_addr(uend_ring + lane31);
+    const unsigned st_max = lds_addr(maxring + lane31);
+    const unsigned st_emit_row = lds_addr(my_row);
+    const int st_pL0 = o0 + lane31 + my_sm.L;  // (frame + L) of this lane's frame in tile 0
+    const unsigned st_key_lo = s_ok ? (unsigned)~my_sm.tf : 0u;
+    int *const st_out = (half == 0 ? reinterpret_cast<int *>(a.scores) : a.ids) + o0 + lane31;
+    const unsigned st_a_off = (unsigned)a_off;
+    const bool st_p0 = wave < n_pieces, st_p1 = wave + kWaves < n_pieces && n_pieces <= 2 * kWaves;
+    const bool st_ok = MODE == 0 && NL == 2 && nslots <= 16 && n_pieces <= 2 * kWaves;
+    auto steady_iter = [&](int t) {
+        i32x16 acc[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) acc[l] = (i32x16){};
+        const unsigned x_nxt = xnext(x_cur);
+        const unsigned xa = x_cur + st_a_off, xn = x_nxt + st_a_off;
+        const int f = t - lag;                                     // phases A/B; phase C does f-1
+        const unsigned fb4 = (unsigned)((32 * f) & ring_mask) * 4u;        // byte offset of tile f in a ring row
+        const unsigned fc8 = (unsigned)((32 * (f - 1)) & ring_mask) * 8u;  // ... of tile f-1 in the key ring
+        const unsigned cell0 = st_emit_row + (unsigned)((kl + 32 * (t - 1)) & ring_mask) * (unsigned)sizeof(ring_t);
+        const bool c_wave = wave == ((f - 1) & (kWaves - 1));
+        ring_t fq = 0;
+        int fuend = 0;
+        unsigned long long ckey = 0;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (kb == H) {
+                dma_drain();
+                __syncthreads();
+                const uint8_t *src_tile = seg_src + (int64_t)(t + 2) * tile_src_bytes;
+                const unsigned dst = xnext(x_nxt);
+                if (st_p0) lds_dma16(src_tile + src_off0, dst + wave * 1024);
+                if (st_p1) lds_dma16(src_tile + src_off1, dst + (wave + kWaves) * 1024);
+                if (wave == kWaves - 1 && lane < 32)
+                    lds_dma4(a.utt_end + (int64_t)o0 + 32 * (int64_t)(t + 2) + lane,
+                             __builtin_amdgcn_readfirstlane(lds_addr(uend_ring + ((32 * (t + 2)) & ring_mask))));
+            }
+            const i32x4 av = aq[0];
+#pragma unroll
+            for (int i = 0; i + 1 < PF; ++i) aq[i] = aq[i + 1];
+            const int nk = kb + PF;
+            aq[PF - 1] = *(lds_frag *)(size_t)(nk < NKB ? xa + nk * 32 : xn + (nk - NKB) * 32);
+            if (kb == H) {  // finishing phase A: this lane's cell of tile f, reset; utt_end
+                lds_ring *cell = (lds_ring *)(size_t)(st_fin_row + fb4 * (unsigned)(sizeof(ring_t) / 4));
+                fq = *cell;
+                *cell = 0;
+                if (fb4 == 0) {  // wave-uniform: tile f owns the overflow cells
+                    fq += cell[a.ring];
+                    cell[a.ring] = 0;
+                }
+                fuend = *(lds_i32 *)(size_t)(st_uend + fb4);
+            }
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+                acc[l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b[kb][l], acc[l], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (r * NKB / 16 != kb) continue;  // compile-time after unrolling
+                const int c = (r & 3) + 8 * (r >> 2);
+                lds_ring *cell = (lds_ring *)(size_t)cell0 + c;
+                if (NL == 2)
+                    __hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned int *)cell, (unsigned int)v[r],
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else
+                    __hip_atomic_fetch_add((lds_u64 *)cell, (unsigned long long)(long long)v[r], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (kb == ((H + 2 < NKB) ? H + 2 : NKB - 1)) {  // finishing phase B
+                float x;
+                if (NL == 2) {
+                    x = (float)fq * my_sm.inv_scale;
+                } else {
+                    const long long qq = fq;
+                    x = __builtin_fmaf((float)(int)(qq >> 24), 16777216.0f, (float)((unsigned)qq & 0xffffffu)) *
+                        my_sm.inv_scale;
+                }
+                const float raw = (st_pL0 + 32 * f <= fuend) ? x : 0.0f;  // zero tail
+                const float sc = raw + my_sm.cf;
+                unsigned u = __builtin_bit_cast(unsigned, sc);
+                u ^= (unsigned)((int)u >> 31) | 0x80000000u;
+                const unsigned long long key = ((unsigned long long)(s_ok ? u : 0u) << 32) | st_key_lo;
+                __hip_atomic_fetch_max((lds_u64 *)(size_t)(st_max + fb4 * 2u), key, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (kb == ((H + 3 < NKB) ? H + 3 : NKB - 1) && c_wave) {  // phase C: read + reset the keys
+                lds_u64 *kc = (lds_u64 *)(size_t)(st_max + fc8);
+                ckey = *kc;
+                *kc = 0;  // (both halves read before either write: LDS ops of a wave are in order)
+            }
+            if (kb == ((H + 4 < NKB) ? H + 4 : NKB - 1) && c_wave) {  // phase C: decode + store
+                unsigned u = (unsigned)(ckey >> 32);
+                u ^= (~(unsigned)((int)u >> 31)) | 0x80000000u;
+                st_out[32 * (f - 1)] = half == 0 ? (int)u : (int)~(unsigned)ckey;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int x = acc[NL - 1][r];
+#pragma unroll
+            for (int l = NL - 2; l >= 0; --l) x = x * 256 + acc[l][r];
+            v[r] = x;
+        }
+        x_cur = x_nxt;
+    };
+
     if (nT > 0) stage(0, xb0);
     if (nT > 1) stage(1, xnext(xb0));
     dma_drain();
@@ -422,7 +542,11 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
     }
     for (int t = 0; t < nT; ++t) {
         const bool interior = no_pad && 32 * (t - 1) >= lmax1 && 32 * (t - 1) + 35 < nOut;
-        if (interior)
+        // (phase C stores tile t-lag-1 unconditionally: all of its frames must be outputs)
+        const bool steady = st_ok && interior && t + 2 < nT && t - lag >= 1 && 32 * (t - lag) <= nOut;
+        if (steady)
+            steady_iter(t);
+        else if (interior)
             tile_iter(t, true, true, t - lag);
         else
             tile_iter(t, t > 0, false, t - lag);
