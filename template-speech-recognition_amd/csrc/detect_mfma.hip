@@ -51,6 +51,22 @@
 #ifndef TSR_ABL
 #define TSR_ABL 0
 #endif
+// Development stamps (never in the shipped build): -DTSR_STAMP accumulates s_memtime deltas of
+// the steady-state iteration's phases per wave and dumps them to the file $TSR_STAMP_OUT.
+#ifdef TSR_STAMP
+#include <stdlib.h>
+#define TSR_STAMP_AT(i)                                                                  \
+    {                                                                                    \
+        unsigned long long _t;                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        st_sum[i] += _t - st_last;                                                       \
+        st_last = _t;                                                                    \
+    }
+#else
+#define TSR_STAMP_AT(i)
+#endif
 
 namespace {
 
@@ -92,6 +108,7 @@ struct FastArgs {
     int32_t *ids;
     float *all;              // [M][P] per-template scores (G == 1, optional)
     float *raw_frag;         // [n_frag][P] partial raw scores (G > 1)
+    unsigned long long *dbg; // TSR_STAMP builds only
 };
 
 // LDS-DMA (global_load_lds): `size` bytes per lane straight into LDS, destination =
@@ -337,11 +354,30 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
     const bool no_pad = __all(slot >= 0);
     const int lmax1 = a.lmax1;
     i32x4 aq[PF];
-    i32x16 v = {};
 
     unsigned x_cur = xb0;  // LDS address of tile t; t+1 and t+2 follow in the 3-buffer rotation
-    auto tile_iter = [&](int t, bool do_emit, bool interior, int fin) {
-        i32x16 acc[NL];
+    // Two accumulator sets alternate between tiles: `acc` receives tile t's MFMAs while `pacc`
+    // holds tile t-1's sums for the emission.  With two limbs pacc keeps the raw limb sums and
+    // each element is combined (acc1*256 + acc0, exact int32) right before its atomic: no combine
+    // burst waits for the last MFMA of a tile and the next tile's MFMAs can issue while the old
+    // ones drain.  With three limbs two raw sets do not fit the register file, so the tile is
+    // folded into limb 0 at its end (`fold`) and only those 16 registers stay live.
+    auto combine = [&](const i32x16 (&pa)[NL], int r) -> int {
+        if (NL != 2) return pa[0][r];
+        return pa[NL - 1][r] * 256 + pa[0][r];
+    };
+    auto fold = [&](i32x16 (&acc)[NL]) {
+        if (NL == 2) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int x = acc[NL - 1][r];
+#pragma unroll
+            for (int l = NL - 2; l >= 0; --l) x = x * 256 + acc[l][r];
+            acc[0][r] = x;
+        }
+    };
+    auto tile_iter = [&](int t, const i32x16 (&pacc)[NL], i32x16 (&acc)[NL], bool do_emit, bool interior,
+                         int fin) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) acc[l] = (i32x16){};
         const unsigned x_nxt = xnext(x_cur);
@@ -380,11 +416,12 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
                     const int c = (r & 3) + 8 * (r >> 2);
                     ring_t *cell = cell0 + c;
                     if (!interior) cell = ((unsigned)(first + c) < (unsigned)nOut) ? cell : dcell0 + c;
+                    const int vr = combine(pacc, r);
                     if (NL == 2)
-                        atomicAdd(reinterpret_cast<unsigned int *>(cell), (unsigned int)v[r]);
+                        atomicAdd(reinterpret_cast<unsigned int *>(cell), (unsigned int)vr);
                     else
                         atomicAdd(reinterpret_cast<unsigned long long *>(cell),
-                                  (unsigned long long)(long long)v[r]);
+                                  (unsigned long long)(long long)vr);
                 }
             }
             if (!(TSR_ABL & 4)) {
@@ -402,13 +439,7 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
 #pragma unroll
             for (int l = 0; l < NL; ++l) asm volatile("" : "+v"(acc[l]));
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int x = acc[NL - 1][r];
-#pragma unroll
-            for (int l = NL - 2; l >= 0; --l) x = x * 256 + acc[l][r];
-            v[r] = x;
-        }
+        fold(acc);
         x_cur = x_nxt;
     };
 
@@ -436,8 +467,21 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
     const unsigned st_a_off = (unsigned)a_off;
     const bool st_p0 = wave < n_pieces, st_p1 = wave + kWaves < n_pieces && n_pieces <= 2 * kWaves;
     const bool st_ok = MODE == 0 && NL == 2 && nslots <= 16 && n_pieces <= 2 * kWaves;
-    auto steady_iter = [&](int t) {
-        i32x16 acc[NL];
+#ifdef TSR_STAMP
+    unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0}, st_last = 0;
+#endif
+    const uint8_t *st_src0 = nullptr, *st_src1 = nullptr;  // set where the steady range is known
+    const int32_t *st_usrc = nullptr;
+    unsigned st_udst0 = 0;
+    auto steady_iter = [&](int t, const i32x16 (&pacc)[NL], i32x16 (&acc)[NL]) {
+#ifdef TSR_STAMP
+        {
+            unsigned long long _t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");
+            if (st_last) st_sum[5] += _t - st_last;  // between iterations (loop control, combine)
+            st_last = _t;
+        }
+#endif
 #pragma unroll
         for (int l = 0; l < NL; ++l) acc[l] = (i32x16){};
         const unsigned x_nxt = xnext(x_cur);
@@ -453,15 +497,21 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             if (kb == H) {
+                TSR_STAMP_AT(0)  // first half: steps 0..H-1
                 dma_drain();
+                TSR_STAMP_AT(1)  // wait for this wave's DMA
                 __syncthreads();
-                const uint8_t *src_tile = seg_src + (int64_t)(t + 2) * tile_src_bytes;
+                TSR_STAMP_AT(2)  // barrier
+                // DMA of tile t+2: per-lane source pointers advance by one tile per iteration
                 const unsigned dst = xnext(x_nxt);
-                if (st_p0) lds_dma16(src_tile + src_off0, dst + wave * 1024);
-                if (st_p1) lds_dma16(src_tile + src_off1, dst + (wave + kWaves) * 1024);
+                if (st_p0) lds_dma16(st_src0, dst + wave * 1024);
+                if (st_p1) lds_dma16(st_src1, dst + (wave + kWaves) * 1024);
                 if (wave == kWaves - 1 && lane < 32)
-                    lds_dma4(a.utt_end + (int64_t)o0 + 32 * (int64_t)(t + 2) + lane,
-                             __builtin_amdgcn_readfirstlane(lds_addr(uend_ring + ((32 * (t + 2)) & ring_mask))));
+                    lds_dma4(st_usrc, st_udst0 + (unsigned)((32 * (t + 2)) & ring_mask) * 4u);
+                st_src0 += tile_src_bytes;
+                st_src1 += tile_src_bytes;
+                st_usrc += 32;
+                TSR_STAMP_AT(3)  // DMA issue
             }
             const i32x4 av = aq[0];
 #pragma unroll
@@ -486,11 +536,12 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
                 if (r * NKB / 16 != kb) continue;  // compile-time after unrolling
                 const int c = (r & 3) + 8 * (r >> 2);
                 lds_ring *cell = (lds_ring *)(size_t)cell0 + c;
+                const int vr = combine(pacc, r);
                 if (NL == 2)
-                    __hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned int *)cell, (unsigned int)v[r],
+                    __hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned int *)cell, (unsigned int)vr,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 else
-                    __hip_atomic_fetch_add((lds_u64 *)cell, (unsigned long long)(long long)v[r], __ATOMIC_RELAXED,
+                    __hip_atomic_fetch_add((lds_u64 *)cell, (unsigned long long)(long long)vr, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (kb == ((H + 2 < NKB) ? H + 2 : NKB - 1)) {  // finishing phase B
@@ -522,14 +573,9 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int x = acc[NL - 1][r];
-#pragma unroll
-            for (int l = NL - 2; l >= 0; --l) x = x * 256 + acc[l][r];
-            v[r] = x;
-        }
+        fold(acc);
         x_cur = x_nxt;
+        TSR_STAMP_AT(4)  // second half: steps H..NKB-1 + combine
     };
 
     if (nT > 0) stage(0, xb0);
@@ -540,32 +586,60 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
 #pragma unroll
         for (int i = 0; i < PF; ++i) aq[i] = *reinterpret_cast<const i32x4 *>(smem + a_off + i * 32);
     }
-    for (int t = 0; t < nT; ++t) {
+    // steady range [ts0, ts1): interior tile, DMA of t+2 due, phases A/B/C active and phase C's
+    // tile t-lag-1 entirely inside the outputs (it stores unconditionally)
+    int ts0 = max(lag + 1, (lmax1 + 31) / 32 + 1), ts1 = min(nT - 2, (nOut - 36) / 32 + 2);
+    if (!st_ok || !no_pad) ts1 = ts0;
+    while (ts1 > ts0 && !(32 * (ts1 - 2) + 35 < nOut && 32 * (ts1 - 1 - lag) <= nOut)) --ts1;
+    // DMA source pointers of the first steady iteration (tile ts0 + 2)
+    st_src0 = seg_src + (int64_t)(ts0 + 2) * tile_src_bytes + src_off0;
+    st_src1 = seg_src + (int64_t)(ts0 + 2) * tile_src_bytes + src_off1;
+    st_usrc = a.utt_end + (int64_t)o0 + 32 * (int64_t)(ts0 + 2) + lane;
+    st_udst0 = __builtin_amdgcn_readfirstlane(lds_addr(uend_ring));
+    i32x16 accA[NL], accB[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) accA[l] = (i32x16){};
+    auto one_iter = [&](int t, const i32x16 (&pacc)[NL], i32x16 (&acc)[NL]) {
         const bool interior = no_pad && 32 * (t - 1) >= lmax1 && 32 * (t - 1) + 35 < nOut;
-        // (phase C stores tile t-lag-1 unconditionally: all of its frames must be outputs)
-        const bool steady = st_ok && interior && t + 2 < nT && t - lag >= 1 && 32 * (t - lag) <= nOut;
-        if (steady)
-            steady_iter(t);
+        if (t >= ts0 && t < ts1)
+            steady_iter(t, pacc, acc);
         else if (interior)
-            tile_iter(t, true, true, t - lag);
+            tile_iter(t, pacc, acc, true, true, t - lag);
         else
-            tile_iter(t, t > 0, false, t - lag);
-    }
-    // ---- drain: emit the last tile, then finish what is left ------------------------------------
-    if (nT > 0 && !(TSR_ABL & 1)) {
+            tile_iter(t, pacc, acc, t > 0, false, t - lag);
+    };
+    // the last tile's sums go through the skew reduction after the loop (nothing left to overlap)
+    auto emit_last = [&](const i32x16 (&pacc)[NL]) {
+        if (TSR_ABL & 1) return;
         const int first = kl + 32 * (nT - 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c = (r & 3) + 8 * (r >> 2);
             ring_t *cell = (((unsigned)(first + c) < (unsigned)nOut) ? my_row : dummy_row) + (first & ring_mask) + c;
+            const int vr = combine(pacc, r);
             if (NL == 2)
-                atomicAdd(reinterpret_cast<unsigned int *>(cell), (unsigned int)v[r]);
+                atomicAdd(reinterpret_cast<unsigned int *>(cell), (unsigned int)vr);
             else
-                atomicAdd(reinterpret_cast<unsigned long long *>(cell), (unsigned long long)(long long)v[r]);
+                atomicAdd(reinterpret_cast<unsigned long long *>(cell), (unsigned long long)(long long)vr);
         }
+    };
+    int t = 0;
+    for (; t + 1 < nT; t += 2) {  // two tiles per trip: the accumulator sets swap roles
+        one_iter(t, accA, accB);
+        one_iter(t + 1, accB, accA);
+    }
+    if (t < nT) {
+        one_iter(t, accA, accB);
+        emit_last(accB);
+    } else if (nT > 0) {
+        emit_last(accA);
     }
     dma_drain();
     __syncthreads();
+#ifdef TSR_STAMP
+    if (a.dbg && lane == 0)
+        for (int i = 0; i < 6; ++i) a.dbg[((size_t)blockIdx.x * kWaves + wave) * 6 + i] = st_sum[i];
+#endif
     const int nF = (TSR_ABL & 48) ? 0 : (nOut + 31) >> 5;
     const int f0 = max(nT - lag, 0);  // tiles < f0 went through phase AB inside the loop
     if (!(TSR_ABL & 4))
@@ -937,6 +1011,11 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
     if (fragments) TSR_TRY(tsr_scratch(ctx, 0, (size_t)fb->n_frag * P * sizeof(float), &raw_frag));
     const int grid = nseg * fb->G;
     const bool flat = (SB == Dp) && fb->n_phase == 1;
+    unsigned long long *d_dbg = nullptr;
+#ifdef TSR_STAMP
+    TSR_HIP(hipMalloc(reinterpret_cast<void **>(&d_dbg), (size_t)grid * kWaves * 6 * 8));
+    TSR_HIP(hipMemsetAsync(d_dbg, 0, (size_t)grid * kWaves * 6 * 8, ctx->stream));
+#endif
     for (int ph = 0; ph < fb->n_phase; ++ph) {
         FastArgs a;
         memset(&a, 0, sizeof a);
@@ -960,6 +1039,7 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
         a.ring = ring;
         a.lag = lag;
         a.lmax1 = bank->Lmax - 1;
+        a.dbg = d_dbg;
         if (fragments) {
             a.raw_frag = (float *)raw_frag;
         } else {
@@ -984,6 +1064,20 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
         }
         TSR_TRY(s);
     }
+#ifdef TSR_STAMP
+    if (const char *path = getenv("TSR_STAMP_OUT")) {
+        std::vector<unsigned long long> h((size_t)grid * kWaves * 6);
+        TSR_HIP(hipStreamSynchronize(ctx->stream));
+        TSR_HIP(hipMemcpy(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE *fp = fopen(path, "w")) {
+            for (size_t w = 0; w < (size_t)grid * kWaves; ++w)
+                fprintf(fp, "%zu %zu %llu %llu %llu %llu %llu %llu\n", w / kWaves, w % kWaves, h[w * 6], h[w * 6 + 1],
+                        h[w * 6 + 2], h[w * 6 + 3], h[w * 6 + 4], h[w * 6 + 5]);
+            fclose(fp);
+        }
+    }
+    (void)hipFree(d_dbg);
+#endif
     if (fragments) {
         hipLaunchKernelGGL(frag_epilogue_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0,
                            ctx->stream, (const float *)raw_frag, P, bank->M, fb->d_frag_ptr, fb->d_frag_idx,
