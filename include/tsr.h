@@ -160,6 +160,18 @@ int tsr_part_features(tsr_ctx *ctx, const tsr_parts *parts, const uint8_t *X, in
 int tsr_corpus_part_features(tsr_ctx *ctx, const tsr_parts *parts, const tsr_corpus *edges,
                              int threshold, int fast, int r0, int r1, const uint8_t *graph, int g0,
                              int g1, tsr_corpus **out);
+/* The corpus chain has two coders with IDENTICAL results (the part ids of code_parts.pyx:70-135
+ * followed by np.argmax): the VALU kernel that forms the reference's f64 sums, and the MFMA coder
+ * that finds the index with exact 16-bit integer sums and re-evaluates in f64 only the locations
+ * whose two best parts lie within the rounding window.  AUTO takes the MFMA coder whenever the
+ * tables fit it (E == 8, K <= 63, P0*ceil(P1/2) <= 16, finite tables); MFMA makes the call fail
+ * with TSR_ERR_UNSUPPORTED instead of falling back.
+ * tsr_parts_info: whether the MFMA coder is available and, for the latest
+ * tsr_corpus_part_features, the number of live-or-not patch locations scanned and how many of
+ * them went through the f64 re-evaluation (-1: the VALU kernel ran).  Any pointer may be NULL. */
+enum { TSR_PARTS_AUTO = 0, TSR_PARTS_VALU = 1, TSR_PARTS_MFMA = 2 };
+int tsr_parts_set_mode(tsr_parts *parts, int mode);
+int tsr_parts_info(const tsr_parts *parts, int *mfma_available, int64_t *locations, int64_t *rechecked);
 /* Read back a corpus: feature bytes u8 [sum T_n, D]; its shape (frame_offsets i64 [N+1], may be NULL). */
 int tsr_corpus_download_feats(tsr_ctx *ctx, const tsr_corpus *corpus, uint8_t *feats);
 int tsr_corpus_shape(const tsr_corpus *corpus, int64_t *N, int64_t *D, int64_t *frame_offsets);

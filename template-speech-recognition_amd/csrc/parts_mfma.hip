@@ -1,0 +1,496 @@
+// parts_mfma.hip -- the patch coder of the fused front-end on the matrix cores.
+//
+// What the reference computes (code_parts.pyx:70-135 / :247-295, then np.argmax at
+// get_train_data.py:2621 / :184): for every patch location and part k the f64 sum, in the
+// order i -> j -> z, of log_parts[k] where the edge is set and log_invparts[k] where it is
+// not; the chain keeps only the INDEX of the first maximum.  The VALU kernel in parts.hip
+// reproduces those sums bit for bit, one LDS read + one f64 add per (location, part, cell):
+// 12 ms for BASELINE config 3.  Here the index is found without forming the f64 sums:
+//
+//   1. S_k = sum_q lip[k,q] + sum_q x_q (lp - lip)[k,q].  The differences are quantised to
+//      16-bit fixed point (two int8 limbs, scale s) and the base sums to integers, so that
+//      I_k = B_k + sum_q x_q dq[k,q] is an exact integer computed by v_mfma_i32_32x32x32_i8
+//      with |I_k/s - S_k| <= (0.5*count + 0.75)/s, count = number of set edges in the patch
+//      (the +0.75 covers the rounding of B_k and of the reference's own f64 sum).
+//   2. A location whose best and second-best I differ by more than count + 2 has a unique
+//      maximiser that no rounding can overturn: its index is final.  Every other location
+//      (exact ties between duplicate parts included) goes, with the bit mask of the parts
+//      inside the window, onto a list that `code_parts_recheck_kernel` re-evaluates with the
+//      reference's sequential f64 sums -- so the part ids are the reference's in all cases.
+//   3. The edge count comes out of the same GEMM (a row of ones); code_parts_fast's slot 0
+//      (sum_k (S_k - 1), code_parts.pyx:289-293) is bounded from the same integers and sends
+//      the location to the list in the (for log-probability tables impossible) case that it
+//      could win.
+//
+// GEMM shape.  The resident corpus is a byte stream with row stride Dp (a multiple of 16) and
+// E = 8 edge bytes per frequency bin, i.e. a stream of 8-byte "positions", S = Dp/8 per frame.
+// For the patch at position p, cell (i, j, z) is byte (p + i*S + j)*8 + z: the same offset for
+// every location, so 32 consecutive positions form the N dimension of one MFMA (B operand:
+// lane n reads 16 bytes = 2 bins x 8 edges at its own position), the K dimension runs over
+// (patch row i, bin pair c) and the M dimension over the parts (A operand: weights, held in
+// registers for the life of the workgroup).  Positions whose bin index exceeds X1 - P1 are
+// computed and dropped (41 of 46 are live for 45 bins).  The result layout puts the parts of
+// one location into the registers of one lane (and its partner lane + 32), so the argmax is
+// per-lane VALU work: a packed key (I_k << 6 | k), v_max + v_med3 per part.
+//
+// Frames are staged through LDS in chunks of CH frames (+ P0 - 1 rows of overlap); chunks are
+// handed out by an atomic counter (persistent workgroups, 2 per CU).
+#include "tsr_internal.h"
+
+#include <cmath>
+#include <vector>
+
+namespace {
+
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWG = 256;  // 4 waves
+constexpr int kWaves = kWG / 64;
+constexpr int kPad = 256;             // zeroed bytes behind the staged rows (over-read of the last bin pairs)
+constexpr int kVInv = -(1 << 25) + 1024;  // value of the empty part slots: below every real score
+constexpr int kVMax = 1 << 24;            // |I_k| bound of the real slots
+
+struct PmArgs {
+    const uint8_t *X;  // resident corpus [P][Dp]
+    int64_t P;
+    int Dp, S, N1, P0, CH, nchunks;
+    const int32_t *utt_end;
+    const i32x4 *Wq;    // [mt 2][kb NKB][limb 2][lane 64]
+    const int32_t *Kc;  // [half 2][mt 2][r 16]: (B_m << 6) | m
+    int G1, NG;         // K-groups: (patch row i, bin pair c), g = i*G1 + c, NG of them
+    int K;
+    unsigned threshold;
+    int fast;
+    float o0_const, o0_slack;  // code_parts_fast: slot 0 in units (see host prep)
+    int n_inv;                 // empty part slots (incl. the row of ones)
+    int *work;                 // [0] chunk counter, [1] list length
+    int32_t *argmax;           // [P][N1]
+    uint32_t *list;            // [n][4]: location, full, mask lo, mask hi
+};
+
+__device__ __forceinline__ int med3(int a, int b, int c)
+{
+    int d;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+template <int NKB>
+__global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, half = lane >> 5;
+    const int row_bytes = (a.CH + a.P0 - 1) * a.Dp;
+    uint8_t *rows = smem;
+    int32_t *kcl = reinterpret_cast<int32_t *>(smem + row_bytes + kPad);  // [2][2][16]
+    int32_t *uendl = kcl + 64;                                             // [CH]
+    int32_t *chunkl = uendl + a.CH;
+
+    // weights: register-stationary for the life of the workgroup
+    i32x4 W[2][NKB][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int l = 0; l < 2; ++l) W[mt][kb][l] = a.Wq[((mt * NKB + kb) * 2 + l) * 64 + lane];
+    int boff[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {  // byte offset of this lane's K-group inside the patch (padding groups: weights are 0)
+        const int g = 2 * kb + half;
+        boff[kb] = g < a.NG ? ((g / a.G1) * a.S + 2 * (g % a.G1)) * 8 : 0;
+    }
+    if (tid < 64) kcl[tid] = a.Kc[tid];
+
+    const int64_t body = a.P * (int64_t)a.Dp;
+    const int ntiles = a.CH * a.S / 32;
+    const float invS = 1.0f / (float)a.S;
+
+    for (;;) {
+        __syncthreads();  // previous chunk fully consumed (and kcl visible the first time)
+        if (tid == 0) chunkl[0] = atomicAdd(a.work, 1);
+        __syncthreads();
+        const int chunk = chunkl[0];
+        if (chunk >= a.nchunks) break;  // uniform: every wave leaves together
+        const int64_t f0 = (int64_t)chunk * a.CH;
+        {  // stage the chunk: a straight copy of (CH + P0 - 1) rows, zeros behind the corpus
+            const int64_t g0 = f0 * a.Dp;
+            for (int off = tid * 16; off < row_bytes + kPad; off += kWG * 16) {
+                i32x4 v = {0, 0, 0, 0};
+                if (off < row_bytes && g0 + off + 16 <= body) v = *reinterpret_cast<const i32x4 *>(a.X + g0 + off);
+                *reinterpret_cast<i32x4 *>(rows + off) = v;
+            }
+            if (tid < a.CH) uendl[tid] = (f0 + tid < a.P) ? a.utt_end[f0 + tid] : 0;
+        }
+        __syncthreads();
+
+        for (int tile = wave; tile < ntiles; tile += kWaves) {
+            const int lp = tile * 32 + n;  // local position of this lane's location
+            const uint8_t *xa = rows + lp * 8;
+            // One M-tile (32 part slots) at a time, so that only two limb accumulators are live;
+            // the B fragments are re-read from LDS for the second tile (cheap next to 16 MFMAs).
+            // `visit(mt, r, key)` sees the packed key (I << 6 | slot) of each of this lane's slots.
+            int cnt_own = 0;
+            auto tile_pass = [&](auto &&visit) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    i32x16 acc[2] = {};
+#pragma unroll
+                    for (int kb = 0; kb < NKB; ++kb) {
+                        const i32x2 b0 = *reinterpret_cast<const i32x2 *>(xa + boff[kb]);
+                        const i32x2 b1 = *reinterpret_cast<const i32x2 *>(xa + boff[kb] + 8);
+                        const i32x4 b = {b0.x, b0.y, b1.x, b1.y};
+#pragma unroll
+                        for (int l = 0; l < 2; ++l)
+                            acc[l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(W[mt][kb][l], b, acc[l], 0, 0, 0);
+                    }
+                    // keep the two M-tiles apart in the schedule (one accumulator pair live: the
+                    // weights leave no room for two); the SIMD's other wave fills the gaps
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const i32x4 kc = *reinterpret_cast<const i32x4 *>(kcl + (half * 2 + mt) * 16 + r4 * 4);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            visit(mt, r4 * 4 + c, (acc[1][r4 * 4 + c] << 14) + (acc[0][r4 * 4 + c] << 6) + kc[c]);
+                    }
+                    if (mt == 1) cnt_own = acc[0][15];  // the row of ones is slot 63: half 1, mt 1, r 15
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            int best = INT32_MIN, second = INT32_MIN;
+            float vsum = 0.0f;
+            tile_pass([&](int, int, int key) {
+                second = med3(best, second, key);
+                best = max(best, key);
+                if (a.fast) vsum += (float)(key >> 6);
+            });
+            const int obest = __shfl_xor(best, 32), osecond = __shfl_xor(second, 32);
+            const unsigned count = (unsigned)__shfl(cnt_own, n + 32);
+            const int mbest = max(best, obest);
+            const int msecond = max(min(best, obest), max(second, osecond));
+            const int vbest = mbest >> 6;
+            const int window = (int)count + 2;
+            // where is this location?
+            int fl = (int)((float)lp * invS);
+            int j = lp - fl * a.S;
+            if (j < 0) {
+                --fl;
+                j += a.S;
+            } else if (j >= a.S) {
+                ++fl;
+                j -= a.S;
+            }
+            const int64_t f = f0 + fl;
+            const bool live = j < a.N1 && f < a.P && f + a.P0 <= (int64_t)uendl[fl];
+            const bool coded = count >= a.threshold;
+            bool flag = live && coded && (vbest - (msecond >> 6) <= window);
+            bool full = false;
+            if (a.fast) {
+                vsum += __shfl_xor(vsum, 32);
+                // slot 0 = sum_k (S_k - 1) in units, pushed up by its error bound
+                const float o0 = vsum - (float)a.n_inv * (float)kVInv - (float)count + a.o0_const +
+                                 (float)a.K * (0.5f * (float)count + 1.0f) + a.o0_slack;
+                full = live && coded && o0 >= (float)(vbest - window);
+                flag = flag || full;
+            }
+            const int64_t loc = f * a.N1 + j;
+            if (__builtin_amdgcn_ballot_w64(flag) != 0) {
+                // rare (a few percent of the tiles): some location needs the f64 re-evaluation.  Run
+                // the tile again to collect, per location, the parts inside the window.
+                const int thr = vbest - window;
+                unsigned mlo = 0, mhi = 0;
+                tile_pass([&](int mt, int r, int key) {
+                    const unsigned bit = ((key >> 6) >= thr) ? (1u << (8 * (r >> 2) + half * 4 + (r & 3))) : 0u;
+                    if (mt == 0)
+                        mlo |= bit;
+                    else
+                        mhi |= bit;
+                });
+                mlo |= __shfl_xor(mlo, 32);
+                mhi |= __shfl_xor(mhi, 32);
+                if (flag && half == 0) {
+                    const int slot = atomicAdd(a.work + 1, 1);
+                    uint32_t *e = a.list + (size_t)slot * 4;
+                    e[0] = (uint32_t)loc;
+                    e[1] = full ? 1u : 0u;
+                    e[2] = mlo;
+                    e[3] = mhi;
+                }
+            }
+            if (live && half == 0 && !flag) a.argmax[loc] = coded ? (mbest & 63) + 1 : 0;
+        }
+    }
+}
+
+// The reference's sequential f64 sums for the listed locations, restricted to the parts inside
+// the window (all parts, and slot 0, for `full` entries).  One lane per entry: the sum over the
+// patch cells is sequential by definition, so the parallelism is across entries.  The lane first
+// packs its patch into bit words (LDS, one column per lane) so that the table reads no longer
+// depend on a byte load each, then walks tab_kq [k][q][2] (one part = one contiguous 16*Q-byte
+// run: every cache line serves 8 cells) with 16 loads in flight.
+constexpr int kRcThreads = 128;
+constexpr int kRcWords = 8;  // Q <= 256 cells (16 K-groups of 16)
+
+__global__ __launch_bounds__(kRcThreads) void code_parts_recheck_kernel(
+    const uint8_t *__restrict__ X, int Dp, int E, int P0, int P1, int N1, const double *__restrict__ tab_kq /*[K][Q][2]*/,
+    int K, int fast, const uint32_t *__restrict__ list, const int *__restrict__ work, int32_t *__restrict__ argmax)
+{
+    __shared__ uint32_t xw[kRcWords][kRcThreads];
+    const int n = work[1];
+    const int Q = P0 * P1 * E, rowc = P1 * E;
+    for (int e = blockIdx.x * kRcThreads + threadIdx.x; e < n; e += gridDim.x * kRcThreads) {
+        const uint32_t loc = list[(size_t)e * 4];
+        const bool full = list[(size_t)e * 4 + 1] != 0;
+        uint64_t mask = ((uint64_t)list[(size_t)e * 4 + 3] << 32) | list[(size_t)e * 4 + 2];
+        if (full) mask = ~0ull;
+        const int i0 = (int)(loc / (unsigned)N1), j0 = (int)(loc - (unsigned)i0 * (unsigned)N1);
+        const uint8_t *x0 = X + (int64_t)i0 * Dp + j0 * E;
+        for (int w = 0; w < kRcWords; ++w) xw[w][threadIdx.x] = 0;
+        for (int i = 0; i < P0; ++i)
+            for (int j = 0; j < P1; ++j) {  // E == 8: one bin = one aligned 8-byte word of 0/1 bytes -> 8 bits
+                const uint64_t v = *reinterpret_cast<const uint64_t *>(x0 + (int64_t)i * Dp + j * 8);
+                const uint32_t b8 = (uint32_t)((v * 0x0102040810204080ull) >> 56);
+                const int q = (i * P1 + j) * 8;
+                xw[q >> 5][threadIdx.x] |= b8 << (q & 31);
+            }
+        int bestk = -1;
+        double bestv = 0.0, slot0 = 0.0;
+        if (K < 64) mask &= (1ull << K) - 1;
+        while (mask) {  // every lane walks ITS OWN candidates (ascending k), not the wave's union
+            const int k = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const double *t = tab_kq + (int64_t)k * Q * 2;
+            double acc = 0.0;
+            for (int w = 0; w * 32 < Q; ++w) {
+                const uint32_t bits = xw[w][threadIdx.x];
+                const int nb = min(32, Q - w * 32);
+                int b = 0;
+                for (; b + 16 <= nb; b += 16) {
+                    double v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = t[(w * 32 + b + u) * 2 + ((bits >> (b + u)) & 1)];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) acc += v[u];
+                }
+                for (; b < nb; ++b) acc += t[(w * 32 + b) * 2 + ((bits >> b) & 1)];
+            }
+            slot0 += acc - 1.0;
+            if (bestk < 0 || acc > bestv) {
+                bestv = acc;
+                bestk = k;
+            }
+        }
+        int res = bestk + 1;
+        if (full && fast && !(bestv > slot0)) res = 0;
+        argmax[loc] = res;
+    }
+}
+
+template <int NKB>
+int launch_nkb(tsr_ctx *ctx, const PmArgs &a, size_t lds)
+{
+    TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(code_parts_mfma_kernel<NKB>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = std::min(a.nchunks, 2 * std::max(ctx->cus, 1));
+    hipLaunchKernelGGL(code_parts_mfma_kernel<NKB>, dim3((unsigned)grid), dim3(kWG), lds, ctx->stream, a);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+
+}  // namespace
+
+void tsr_parts_mfma_free(tsr_parts *p)
+{
+    if (p->d_wq) (void)hipFree(p->d_wq);
+    if (p->d_kc) (void)hipFree(p->d_kc);
+    if (p->d_tab_kq) (void)hipFree(p->d_tab_kq);
+    p->d_tab_kq = nullptr;
+    p->d_wq = nullptr;
+    p->d_kc = nullptr;
+    p->mfma_ok = false;
+}
+
+// Quantise the tables for the MFMA coder.  Leaves p->mfma_ok false (and says why in
+// p->mfma_why) when the geometry or the value range is outside what the kernel covers; the
+// caller then keeps to the VALU kernel.  lp / lip are [K][Q] as handed to tsr_parts_create.
+int tsr_parts_mfma_prepare(tsr_ctx *ctx, tsr_parts *p, const double *lp, const double *lip)
+{
+    p->mfma_ok = false;
+    auto no = [&](const char *why) {
+        snprintf(p->mfma_why, sizeof(p->mfma_why), "%s", why);
+        return TSR_OK;
+    };
+    const int64_t K = p->K, P0 = p->P0, P1 = p->P1, E = p->E, Q = P0 * P1 * E;
+    if (E != 8) return no("E != 8 edge bytes per bin");
+    if (K > 63) return no("more than 63 parts");
+    const int64_t G1 = (P1 + 1) / 2, NG = P0 * G1;
+    if (NG > 16) return no("patch larger than 16 K-groups (P0 * ceil(P1/2) > 16)");
+    const int nkb = (int)((NG + 1) / 2);
+    double maxd = 0.0, maxabs = 0.0;
+    for (int64_t i = 0; i < K * Q; ++i) {
+        if (!std::isfinite(lp[i]) || !std::isfinite(lip[i])) return no("non-finite table entry");
+        maxd = std::max(maxd, std::fabs(lp[i] - lip[i]));
+        maxabs = std::max(maxabs, std::max(std::fabs(lp[i]), std::fabs(lip[i])));
+    }
+    std::vector<long double> B((size_t)K, 0.0L);
+    long double bmin = 0, bmax = 0;
+    for (int64_t k = 0; k < K; ++k) {
+        long double s = 0;
+        for (int64_t q = 0; q < Q; ++q) s += (long double)lip[k * Q + q];
+        B[(size_t)k] = s;
+        bmin = k ? std::min(bmin, s) : s;
+        bmax = k ? std::max(bmax, s) : s;
+    }
+    const long double shift_real = (bmin + bmax) / 2;
+    const double spread = (double)(bmax - bmin) / 2;
+    double s = maxd > 0 ? 32512.0 / maxd : 1.0;
+    // |I_k| <= |B_k - shift| s + Q maxd s + 1 must stay below kVMax
+    const double lim = (double)(kVMax - 4096);
+    if ((spread + (double)Q * maxd) * s > lim) s = lim / (spread + (double)Q * maxd);
+    if (!(s > 0) || !std::isfinite(s)) return no("degenerate value range");
+    // the reference's own f64 rounding, in units, must vanish inside the 0.25 the window reserves for it
+    if ((double)Q * 2.3e-16 * ((double)Q * maxabs) * s > 0.2) return no("tables too large for the f64 rounding allowance");
+    const long long shift_units = llroundl(shift_real * (long double)s);
+
+    std::vector<int8_t> wq((size_t)2 * nkb * 2 * 64 * 16, 0);
+    auto wq_at = [&](int mt, int kb, int l, int lane, int byte) -> int8_t & {
+        return wq[(size_t)((((mt * nkb + kb) * 2 + l) * 64 + lane) * 16 + byte)];
+    };
+    for (int m = 0; m < 64; ++m) {
+        const int mt = m / 32, mr = m % 32;
+        for (int64_t g = 0; g < NG; ++g) {
+            const int64_t ip = g / G1, c = g % G1;
+            const int kb = (int)(g / 2), kg = (int)(g % 2);
+            const int lane = kg * 32 + mr;
+            for (int t = 0; t < 16; ++t) {
+                const int64_t jp = 2 * c + t / 8, z = t % 8;
+                if (jp >= P1) continue;
+                const int64_t q = (ip * P1 + jp) * E + z;
+                long long dq;
+                if (m < K) {
+                    dq = llround((lp[m * Q + q] - lip[m * Q + q]) * s);
+                    if (dq > 32512) dq = 32512;   // cannot happen for s <= 32512/maxd; keeps the limbs in range
+                    if (dq < -32512) dq = -32512;
+                } else if (m == 63) {
+                    dq = 1;  // the row of ones: edge count
+                } else {
+                    continue;
+                }
+                const long long hi = (dq + 128) >> 8, lo = dq - hi * 256;
+                wq_at(mt, kb, 0, lane, t) = (int8_t)lo;
+                wq_at(mt, kb, 1, lane, t) = (int8_t)hi;
+            }
+        }
+    }
+    std::vector<int32_t> kc(64);
+    int n_inv = 0;
+    for (int h = 0; h < 2; ++h)
+        for (int mt = 0; mt < 2; ++mt)
+            for (int r = 0; r < 16; ++r) {
+                const int m = mt * 32 + 8 * (r / 4) + h * 4 + (r % 4);
+                long long v;
+                if (m < K) {
+                    v = llroundl(B[(size_t)m] * (long double)s) - shift_units;
+                    if (v > kVMax || v < -kVMax) return no("base sums out of range");
+                } else {
+                    v = kVInv;
+                    ++n_inv;
+                }
+                kc[(size_t)((h * 2 + mt) * 16 + r)] = (int32_t)(v * 64 + m);
+            }
+    p->pm_G1 = (int)G1;
+    p->pm_NG = (int)NG;
+    p->nkb = nkb;
+    p->pm_n_inv = n_inv;
+    // slot 0 of code_parts_fast, sum_k (I_k + shift) - K s, against best + shift: the kernel adds
+    // this constant to sum_k I_k and compares with the (shifted) best
+    p->pm_o0_const = (float)((double)(K - 1) * (double)shift_units - (double)K * s);
+    p->pm_o0_slack = 4096.0f + 1e-6f * (float)((double)K * (double)kVMax);  // f32 summation of up to 64 values below 2^26
+    TSR_HIP(hipSetDevice(ctx->device));
+    TSR_HIP(hipMalloc(&p->d_wq, wq.size()));
+    TSR_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_kc), kc.size() * 4));
+    TSR_HIP(hipMemcpyAsync(p->d_wq, wq.data(), wq.size(), hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(p->d_kc, kc.data(), kc.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<double> tkq((size_t)(K * Q * 2));
+    for (int64_t i = 0; i < K * Q; ++i) {
+        tkq[(size_t)i * 2] = lip[i];
+        tkq[(size_t)i * 2 + 1] = lp[i];
+    }
+    TSR_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_tab_kq), tkq.size() * 8));
+    TSR_HIP(hipMemcpyAsync(p->d_tab_kq, tkq.data(), tkq.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    p->mfma_ok = true;
+    p->mfma_why[0] = 0;
+    return TSR_OK;
+}
+
+// Part ids of every live location of a resident edge stream -> d_argmax [P][N1].
+// Returns TSR_ERR_UNSUPPORTED (nothing enqueued) when this corpus geometry does not fit.
+// d_list must hold 16 bytes per location, d_work two ints.
+int tsr_launch_code_parts_mfma(tsr_ctx *ctx, const tsr_parts *p, const uint8_t *d_X, int64_t P, int64_t X1,
+                               int Dp, const int32_t *d_utt_end, int threshold, int fast, int32_t *d_argmax,
+                               uint32_t *d_list, int *d_work)
+{
+    if (!p->mfma_ok) return TSR_ERR_UNSUPPORTED;
+    const int64_t N1 = X1 - p->P1 + 1;
+    if (P <= 0 || N1 <= 0) return TSR_OK;
+    if (Dp % 16 != 0 || X1 * p->E > Dp || P * N1 >= ((int64_t)1 << 31)) return TSR_ERR_UNSUPPORTED;
+    const int S = Dp / 8;
+    int CH = 0;
+    size_t lds = 0;
+    for (int ch : {64, 32, 16}) {
+        const size_t need = (size_t)(ch + p->P0 - 1) * Dp + kPad + 256 + (size_t)ch * 4 + 16;
+        if (need <= 40 * 1024 || (ch == 16 && need <= 64 * 1024)) {
+            CH = ch;
+            lds = need;
+            break;
+        }
+    }
+    if (!CH) return TSR_ERR_UNSUPPORTED;
+    TSR_HIP(hipMemsetAsync(d_work, 0, 2 * sizeof(int), ctx->stream));
+    PmArgs a;
+    a.X = d_X;
+    a.P = P;
+    a.Dp = Dp;
+    a.S = S;
+    a.N1 = (int)N1;
+    a.P0 = (int)p->P0;
+    a.CH = CH;
+    a.nchunks = (int)((P + CH - 1) / CH);
+    a.utt_end = d_utt_end;
+    a.Wq = reinterpret_cast<const i32x4 *>(p->d_wq);
+    a.Kc = p->d_kc;
+    a.G1 = p->pm_G1;
+    a.NG = p->pm_NG;
+    a.K = (int)p->K;
+    a.threshold = (unsigned)threshold;
+    a.fast = fast ? 1 : 0;
+    a.o0_const = p->pm_o0_const;
+    a.o0_slack = p->pm_o0_slack;
+    a.n_inv = p->pm_n_inv;
+    a.work = d_work;
+    a.argmax = d_argmax;
+    a.list = d_list;
+    int s = TSR_OK;
+    switch (p->nkb) {
+    case 1: s = launch_nkb<1>(ctx, a, lds); break;
+    case 2: s = launch_nkb<2>(ctx, a, lds); break;
+    case 3: s = launch_nkb<3>(ctx, a, lds); break;
+    case 4: s = launch_nkb<4>(ctx, a, lds); break;
+    case 5: s = launch_nkb<5>(ctx, a, lds); break;
+    case 6: s = launch_nkb<6>(ctx, a, lds); break;
+    case 7: s = launch_nkb<7>(ctx, a, lds); break;
+    case 8: s = launch_nkb<8>(ctx, a, lds); break;
+    default: return TSR_ERR_UNSUPPORTED;
+    }
+    TSR_TRY(s);
+    hipLaunchKernelGGL(code_parts_recheck_kernel, dim3((unsigned)(8 * std::max(ctx->cus, 1))), dim3(kRcThreads), 0, ctx->stream,
+                       d_X, Dp, (int)p->E, (int)p->P0, (int)p->P1, (int)N1, p->d_tab_kq, (int)p->K, fast ? 1 : 0,
+                       (const uint32_t *)d_list, (const int *)d_work, d_argmax);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}

@@ -168,7 +168,7 @@ void dev_free(void *p)
     if (p) (void)hipFree(p);
 }
 
-enum { SLOT_RAW = 0, SLOT_IN = 1, SLOT_W = 2, SLOT_OUT = 3, SLOT_AUX = 4, SLOT_AUX2 = 5 };
+enum { SLOT_RAW = 0, SLOT_IN = 1, SLOT_W = 2, SLOT_OUT = 3, SLOT_AUX = 4, SLOT_AUX2 = 5, SLOT_LIST = 6, SLOT_CNT = 7 };
 
 }  // namespace
 
@@ -612,11 +612,29 @@ TSR_API int tsr_parts_create(tsr_ctx *ctx, const double *lp, const double *lip, 
     p->E = E;
     int s = dev_upload(ctx, &p->d_tab, tab.data(), tab.size());
     if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
+    if (s == TSR_OK) s = tsr_parts_mfma_prepare(ctx, p, lp, lip);
     if (s != TSR_OK) {
         tsr_parts_destroy(p);
         return s;
     }
     *out = p;
+    return TSR_OK;
+}
+
+TSR_API int tsr_parts_set_mode(tsr_parts *p, int mode)
+{
+    TSR_REQUIRE(p, "tsr_parts_set_mode: null pointer");
+    TSR_REQUIRE(mode == TSR_PARTS_AUTO || mode == TSR_PARTS_VALU || mode == TSR_PARTS_MFMA, "tsr_parts_set_mode: unknown mode %d", mode);
+    p->mode = mode;
+    return TSR_OK;
+}
+
+TSR_API int tsr_parts_info(const tsr_parts *p, int *mfma_available, int64_t *locations, int64_t *rechecked)
+{
+    TSR_REQUIRE(p, "tsr_parts_info: null pointer");
+    if (mfma_available) *mfma_available = p->mfma_ok ? 1 : 0;
+    if (locations) *locations = p->last_locations;
+    if (rechecked) *rechecked = p->last_rechecked;
     return TSR_OK;
 }
 
@@ -628,6 +646,7 @@ TSR_API int tsr_parts_destroy(tsr_parts *p)
     (void)hipSetDevice(p->device);
     (void)hipDeviceSynchronize();
     dev_free(p->d_tab);
+    tsr_parts_mfma_free(p);
     delete p;
     return TSR_OK;
 }
@@ -793,16 +812,47 @@ TSR_API int tsr_corpus_part_features(tsr_ctx *ctx, const tsr_parts *parts, const
         s = tsr_scratch(ctx, SLOT_AUX2, (size_t)(K * K), &dG);
         if (s == TSR_OK && hipMemcpyAsync(dG, graph, (size_t)(K * K), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
     }
-    if (s == TSR_OK && edges->P > 0)
-        s = tsr_launch_code_parts_stream(ctx, parts, edges->d_feats, edges->P, X1, edges->Dp, edges->d_utt_end,
-                                         threshold, fast, (int32_t *)dA);
+    // part ids: the MFMA coder when the tables fit it, else (or on request) the VALU kernel
+    bool used_mfma = false;
+    void *dWork = nullptr;
+    if (s == TSR_OK && edges->P > 0) {
+        int sm = TSR_ERR_UNSUPPORTED;
+        if (parts->mode != TSR_PARTS_VALU && parts->mfma_ok) {
+            void *dList = nullptr;
+            sm = tsr_scratch(ctx, SLOT_LIST, (size_t)std::max<int64_t>(edges->P * N1, 1) * 16, &dList);
+            if (sm == TSR_OK) sm = tsr_scratch(ctx, SLOT_CNT, 64, &dWork);
+            if (sm == TSR_OK)
+                sm = tsr_launch_code_parts_mfma(ctx, parts, edges->d_feats, edges->P, X1, edges->Dp, edges->d_utt_end,
+                                                threshold, fast, (int32_t *)dA, (uint32_t *)dList, (int *)dWork);
+            used_mfma = sm == TSR_OK;
+        }
+        if (sm == TSR_ERR_UNSUPPORTED && parts->mode == TSR_PARTS_MFMA) {
+            tsr_set_error("tsr_corpus_part_features: the MFMA coder does not cover this case (%s)",
+                          parts->mfma_ok ? "corpus geometry" : parts->mfma_why);
+            s = TSR_ERR_UNSUPPORTED;
+        } else if (sm == TSR_ERR_UNSUPPORTED) {
+            s = tsr_launch_code_parts_stream(ctx, parts, edges->d_feats, edges->P, X1, edges->Dp, edges->d_utt_end,
+                                             threshold, fast, (int32_t *)dA);
+        } else {
+            s = sm;
+        }
+    }
     if (s == TSR_OK && P_out > 0) {
         if (hipMemsetAsync(cp->d_feats, 0, (size_t)P_out * cp->Dp, ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
         if (s == TSR_OK)
             s = tsr_launch_spread_stream(ctx, (const int32_t *)dA, N1, r0, r1, K, g0, g1, O1, P_out, d_src_row,
                                          d_src_lo, d_src_hi, (const uint8_t *)dG, cp->Dp, cp->d_feats);
     }
+    int work_host[2] = {0, -1};
+    if (s == TSR_OK && used_mfma &&
+        hipMemcpyAsync(work_host, dWork, sizeof(work_host), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        s = TSR_ERR_HIP;
     if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = TSR_ERR_HIP;  // host staging dies here
+    if (s == TSR_OK) {  // bookkeeping for tsr_parts_info (the handle is const for the caller's sake only)
+        tsr_parts *pm = const_cast<tsr_parts *>(parts);
+        pm->last_locations = edges->P * N1;
+        pm->last_rechecked = used_mfma ? work_host[1] : -1;
+    }
     if (s != TSR_OK) {
         if (s == TSR_ERR_HIP) tsr_set_error("tsr_corpus_part_features: device copy/launch failed");
         tsr_corpus_destroy(cp);

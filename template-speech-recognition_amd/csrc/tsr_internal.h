@@ -116,6 +116,16 @@ struct tsr_parts {
     int device = 0;
     int64_t K = 0, P0 = 0, P1 = 0, E = 0;
     double *d_tab = nullptr;  // [q][k][2] = {log_invparts, log_parts}, q = (i*P1+j)*E+z
+    // MFMA coder of the corpus front-end (parts_mfma.hip): 16-bit fixed-point weight limbs
+    int mode = 0;             // TSR_PARTS_AUTO / _VALU / _MFMA (tsr_parts_set_mode)
+    bool mfma_ok = false;     // tables and geometry fit the MFMA coder
+    char mfma_why[96] = {0};  // ... or why not
+    int nkb = 0, pm_G1 = 0, pm_NG = 0, pm_n_inv = 0;
+    float pm_o0_const = 0, pm_o0_slack = 0;
+    void *d_wq = nullptr;     // int8 [mt 2][kb][limb 2][lane 64][16]
+    int32_t *d_kc = nullptr;  // [half 2][mt 2][16]: (base sum << 6) | part
+    double *d_tab_kq = nullptr;  // [k][q][2] = {log_invparts, log_parts}: the re-evaluation's table
+    int64_t last_locations = 0, last_rechecked = -1;  // of the latest tsr_corpus_part_features (-1: VALU kernel ran)
 };
 
 // ---- kernels' host entry points (device pointers, enqueue on ctx->stream) -----
@@ -132,6 +142,12 @@ int tsr_launch_detect_f32(tsr_ctx *ctx, const float *d_F, int64_t T, int64_t D, 
 int tsr_launch_max_detect_examples(tsr_ctx *ctx, const uint8_t *d_F, int64_t N, int64_t T,
                                    int64_t D, const double *d_LF, int64_t L,
                                    const int64_t *d_lengths, double *d_tmp, double *d_out);
+// parts_mfma.hip
+int tsr_parts_mfma_prepare(tsr_ctx *ctx, tsr_parts *p, const double *lp, const double *lip);
+void tsr_parts_mfma_free(tsr_parts *p);
+int tsr_launch_code_parts_mfma(tsr_ctx *ctx, const tsr_parts *p, const uint8_t *d_X, int64_t P, int64_t X1,
+                               int Dp, const int32_t *d_utt_end, int threshold, int fast, int32_t *d_argmax,
+                               uint32_t *d_list, int *d_work);
 // detect_mfma.hip
 int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int NL);
 void tsr_fast_bank_free(tsr_bank *bank);

@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("TSR_HIP_LIB") or os.path.join(_PKG, "lib", "libtsr_hi
 TSR_OK, TSR_ERR_INVALID, TSR_ERR_HIP, TSR_ERR_NO_DEVICE, TSR_ERR_UNSUPPORTED, TSR_ERR_NONFINITE, \
     TSR_ERR_RCCL = range(7)
 TSR_EXACT, TSR_FAST, TSR_W24 = 0, 1, 2
+TSR_PARTS_AUTO, TSR_PARTS_VALU, TSR_PARTS_MFMA = 0, 1, 2
 
 _i32, _i64, _int, _p, _f = C.c_int32, C.c_int64, C.c_int, C.c_void_p, C.c_float
 _pp = C.POINTER(C.c_void_p)
@@ -44,6 +45,8 @@ SIGNATURES = {
     "tsr_spread_graph_patches": [_p, _p, _i64, _i64, _i64, _p],
     "tsr_parts_create": [_p, _p, _p, _i64, _i64, _i64, _i64, _pp],
     "tsr_parts_destroy": [_p],
+    "tsr_parts_set_mode": [_p, _int],
+    "tsr_parts_info": [_p, C.POINTER(_int), C.POINTER(_i64), C.POINTER(_i64)],
     "tsr_part_features": [_p, _p, _p, _i64, _i64, _int, _int, _int, _int, _p, _int, _int, _p, _p],
     "tsr_corpus_part_features": [_p, _p, _p, _int, _int, _int, _int, _p, _int, _int, _pp],
     "tsr_corpus_download_feats": [_p, _p, _p],

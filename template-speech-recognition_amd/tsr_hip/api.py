@@ -251,6 +251,16 @@ class Parts:
         except Exception:
             pass
 
+    def set_mode(self, mode):
+        """Coder of Corpus.part_features: TSR_PARTS_AUTO (MFMA when the tables fit), _VALU, _MFMA."""
+        check(lib().tsr_parts_set_mode(self._h, int(mode)))
+
+    def info(self):
+        """MFMA coder availability and the f64 re-evaluation count of the latest corpus call."""
+        ok, n, r = C.c_int(), C.c_int64(), C.c_int64()
+        check(lib().tsr_parts_info(self._h, C.byref(ok), C.byref(n), C.byref(r)))
+        return dict(mfma_available=bool(ok.value), locations=int(n.value), rechecked=int(r.value))
+
     def features(self, X, threshold, spread=(0, 0), graph=None, grid=(1, 1), fast=False,
                  return_argmax=False):
         """code_parts[_fast] -> argmax -> spread -> [graph] -> [::g0, ::g1] on the GPU

@@ -314,3 +314,94 @@ def test_corpus_part_features_chain(mods, oracle, variant):
     pc.score(bank, tsr_hip.TSR_FAST)
     s, a = pc.download()
     assert rel_err(s, so) <= TOL
+
+
+# ---- the MFMA patch coder: identical part ids to the VALU kernel and to the oracle -------------
+def _oracle_part_chain(oracle, edges, lp, lip, thr, spread, grid, fast, K):
+    P0, P1 = lp.shape[1], lp.shape[2]
+    want = []
+    for E in edges:
+        F = E.shape[1]
+        if E.shape[0] < P0:
+            want.append(np.zeros((0, ((F - P1 + 1) + grid[1] - 1) // grid[1], K), np.uint8))
+            continue
+        cp_fn = oracle.code_parts_fast if fast else oracle.code_parts
+        am = oracle.argmax_last(cp_fn(E, lp, lip, thr))
+        sp = oracle.spread_patches(am, spread[0], spread[1], K)
+        want.append(np.ascontiguousarray(sp[::grid[0], ::grid[1]]))
+    return want
+
+
+PART_CASES = {
+    # name: (K, patch, F, Ts, threshold, fast, table tweak)
+    "standard": (50, (5, 5, 8), 45, [60, 33, 5, 4, 47], 12, False, None),
+    "fast_variant": (20, (5, 5, 8), 21, [40, 17], 10, True, None),
+    "duplicates": (12, (5, 5, 8), 18, [50, 22], 8, False, "dup"),        # exact ties: first index must win
+    "near_ties": (12, (5, 5, 8), 18, [50, 22], 8, False, "eps"),         # parts 1e-13 apart
+    "one_part": (1, (5, 5, 8), 12, [30], 0, False, None),
+    "k63": (63, (5, 5, 8), 16, [28, 9], 15, False, None),
+    "patch_3x3": (9, (3, 3, 8), 20, [25, 2, 14], 3, False, None),
+    "patch_4x6": (9, (4, 6, 8), 20, [25, 3, 14], 6, True, None),
+    "patch_2x7": (5, (2, 7, 8), 9, [19, 1, 2], 0, False, None),
+    "threshold_never": (6, (5, 5, 8), 12, [20], 201, False, None),
+    "threshold_negative": (6, (5, 5, 8), 12, [20], -1, False, None),     # unsigned compare: never coded
+    "positive_tables": (6, (5, 5, 8), 12, [24], 5, True, "positive"),    # slot 0 of the fast variant can win
+    "wide_range": (10, (5, 5, 8), 12, [24], 5, False, "wide"),
+}
+
+
+@pytest.mark.parametrize("case", sorted(PART_CASES))
+def test_part_coder_mfma(mods, oracle, case):
+    tsr_hip = mods[3]
+    from tsr_hip import synth
+    K, patch, F, Ts, thr, fast, tweak = PART_CASES[case]
+    rng = np.random.default_rng(sum(map(ord, case)))
+    q = rng.uniform(0.05, 0.45, size=(F, 8))
+    edges = [synth.features(rng, T, q) for T in Ts]
+    lp, lip = synth.parts(rng, K, patch)
+    if tweak == "dup":
+        lp[5], lip[5] = lp[2], lip[2]
+        lp[9], lip[9] = lp[2], lip[2]
+    elif tweak == "eps":
+        lp[5], lip[5] = lp[2] * (1 + 1e-13), lip[2]
+        lp[9], lip[9] = lp[2], lip[2] * (1 - 1e-13)
+    elif tweak == "positive":
+        lp, lip = -lp * 0.02, -lip * 0.02     # all sums positive: sum_k (S_k - 1) can exceed max_k S_k
+    elif tweak == "wide":
+        lp[3] *= 40.0                          # one part dominates the value range (coarser fixed point)
+    spread, grid = (1, 2), (2, 1)
+    offs = np.concatenate(([0], np.cumsum(Ts)))
+    corpus = tsr_hip.Corpus(np.concatenate(edges).reshape(int(offs[-1]), -1), offs)
+    parts = tsr_hip.Parts(lp, lip)
+    assert parts.info()["mfma_available"]
+    want = _oracle_part_chain(oracle, edges, lp, lip, thr, spread, grid, fast, K)
+    want_cat = np.concatenate([w.reshape(w.shape[0], w.shape[1] * w.shape[2]) for w in want])
+    got = {}
+    for mode in (tsr_hip.TSR_PARTS_MFMA, tsr_hip.TSR_PARTS_VALU):
+        parts.set_mode(mode)
+        pc = corpus.part_features(parts, thr, spread=spread, grid=grid, fast=fast)
+        got[mode] = pc.download_feats()
+        info = parts.info()
+        assert (info["rechecked"] >= 0) == (mode == tsr_hip.TSR_PARTS_MFMA)
+        assert np.array_equal(got[mode], want_cat), (case, mode)
+        if mode == tsr_hip.TSR_PARTS_MFMA and tweak in ("dup", "eps") and thr <= 8:
+            assert info["rechecked"] > 0          # tied locations must have gone through the f64 sums
+    assert np.array_equal(got[tsr_hip.TSR_PARTS_MFMA], got[tsr_hip.TSR_PARTS_VALU])
+
+
+def test_part_coder_mfma_unsupported_falls_back(mods, oracle):
+    tsr_hip = mods[3]
+    from tsr_hip import synth
+    rng = np.random.default_rng(5)
+    edges = [synth.features(rng, 20, rng.uniform(0.05, 0.45, size=(12, 8)))]
+    lp, lip = synth.parts(rng, 70)                      # more parts than the coder's 63 slots
+    corpus = tsr_hip.Corpus(edges[0].reshape(20, -1), np.array([0, 20]))
+    parts = tsr_hip.Parts(lp, lip)
+    assert not parts.info()["mfma_available"]
+    pc = corpus.part_features(parts, 10, spread=(1, 1))  # AUTO: VALU kernel
+    want = _oracle_part_chain(oracle, edges, lp, lip, 10, (1, 1), (1, 1), False, 70)
+    assert np.array_equal(pc.download_feats(), want[0].reshape(want[0].shape[0], want[0].shape[1] * 70))
+    assert parts.info()["rechecked"] == -1
+    parts.set_mode(tsr_hip.TSR_PARTS_MFMA)
+    with pytest.raises(tsr_hip.TsrError):
+        corpus.part_features(parts, 10, spread=(1, 1))

@@ -22,3 +22,4 @@ for rep in range(3):
     pc.score(bank, tsr_hip.TSR_FAST); ctx.sync(); t3 = time.perf_counter()
     print("N=%d: front-end %.2f ms, bank first %.2f ms, bank again %.3f ms  (part map density %.3f)"
           % (N, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, 0.0 if rep else float(pc.download_feats().mean())))
+print("coder:", parts.info())
