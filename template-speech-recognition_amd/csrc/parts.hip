@@ -226,13 +226,95 @@ int tsr_launch_code_parts_stream(tsr_ctx *ctx, const tsr_parts *parts, const uin
     return TSR_OK;
 }
 
+namespace {
+// K <= 64: the same dilation on 64-bit part masks.  One wave per output frame:
+//   1. the (<= 2*r0+1) source rows of part ids become rows of one-hot masks in LDS (coalesced);
+//   2. lane oj ORs the clipped box of its column (LDS reads only), applies the graph closure in
+//      the reference's order (sequential over the source part, code_parts.pyx:459-503) and parks
+//      the mask in LDS;
+//   3. the lanes write the frame's output row as whole 16-byte chunks (1 byte per (column, part),
+//      zero padding up to Dp_out included) -- no memset beforehand, no scattered byte stores.
+constexpr int kSpreadWaves = 4;
+
+__global__ __launch_bounds__(64 * kSpreadWaves) void spread_mask_kernel(
+    const int32_t *__restrict__ A, int N1, int r0, int r1, int K, int g1, int O1, int64_t P_out,
+    const int32_t *__restrict__ out_src_row, const int32_t *__restrict__ out_src_lo,
+    const int32_t *__restrict__ out_src_hi, const uint64_t *__restrict__ graph_masks /*[K] or null*/, int Dp_out,
+    uint8_t *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t sp_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int R = 2 * r0 + 1;
+    uint64_t *bits = reinterpret_cast<uint64_t *>(sp_smem) + (size_t)wave * ((size_t)R * N1 + O1);  // [R][N1]
+    uint64_t *masks = bits + (size_t)R * N1;                                                        // [O1]
+    const int64_t pf = (int64_t)blockIdx.x * kSpreadWaves + wave;
+    const bool on = pf < P_out;
+    int lo0 = 0, hi0 = 0;
+    if (on) {
+        const int i = out_src_row[pf];
+        lo0 = max(i - r0, out_src_lo[pf]);
+        hi0 = min(i + r0 + 1, out_src_hi[pf]);
+        for (int x0 = lo0; x0 < hi0; ++x0)
+            for (int c = lane; c < N1; c += 64) {
+                const int p = A[(int64_t)x0 * N1 + c];
+                bits[(x0 - lo0) * N1 + c] = p > 0 ? 1ull << (p - 1) : 0ull;
+            }
+    }
+    __syncthreads();
+    if (on)
+        for (int oj = lane; oj < O1; oj += 64) {
+            const int j = oj * g1;
+            const int lo1 = max(j - r1, 0), hi1 = min(j + r1 + 1, N1);
+            uint64_t m = 0;
+            for (int x0 = 0; x0 < hi0 - lo0; ++x0)
+                for (int x1 = lo1; x1 < hi1; ++x1) m |= bits[x0 * N1 + x1];
+            if (graph_masks)
+                for (int a = 0; a < K; ++a)
+                    if ((m >> a) & 1) m |= graph_masks[a];
+            masks[oj] = m;
+        }
+    __syncthreads();
+    if (!on) return;
+    uint8_t *row = out + pf * Dp_out;
+    const int nbytes = O1 * K;
+    for (int ci = lane; ci * 16 < Dp_out; ci += 64) {
+        const int b0 = ci * 16;
+        int oj = b0 / K, kk = b0 - oj * K;
+        uint64_t m = oj < O1 ? masks[oj] : 0ull;
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            if (b0 + t < nbytes) w[t >> 2] |= (uint32_t)((m >> kk) & 1) << (8 * (t & 3));
+            if (++kk == K) {
+                kk = 0;
+                ++oj;
+                m = oj < O1 ? masks[oj] : 0ull;
+            }
+        }
+        *reinterpret_cast<uint4 *>(row + b0) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+}  // namespace
+
+// `d_out` rows need no zeroing when this returns with *wrote_all = true (mask kernel); the
+// byte-scatter kernel (K > 64) needs them zeroed and does that itself.
 int tsr_launch_spread_stream(tsr_ctx *ctx, const int32_t *d_A, int64_t N1, int r0, int r1, int64_t K,
                              int g0, int g1, int64_t O1, int64_t P_out, const int32_t *d_src_row,
                              const int32_t *d_src_lo, const int32_t *d_src_hi, const uint8_t *d_graph,
-                             int Dp_out, uint8_t *d_out)
+                             const uint64_t *d_graph_masks, int Dp_out, uint8_t *d_out)
 {
+    (void)g0;
     const int64_t n = P_out * O1;
     if (n <= 0) return TSR_OK;
+    const size_t lds = (size_t)kSpreadWaves * ((size_t)(2 * r0 + 1) * N1 + O1) * 8;
+    if (K <= 64 && lds <= 48 * 1024 && Dp_out % 16 == 0) {
+        hipLaunchKernelGGL(spread_mask_kernel, dim3((unsigned)((P_out + kSpreadWaves - 1) / kSpreadWaves)),
+                           dim3(64 * kSpreadWaves), lds, ctx->stream, d_A, (int)N1, r0, r1, (int)K, g1, (int)O1, P_out,
+                           d_src_row, d_src_lo, d_src_hi, d_graph ? d_graph_masks : nullptr, Dp_out, d_out);
+        TSR_HIP(hipGetLastError());
+        return TSR_OK;
+    }
+    TSR_HIP(hipMemsetAsync(d_out, 0, (size_t)P_out * Dp_out, ctx->stream));
     hipLaunchKernelGGL(spread_stream_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads),
                        0, ctx->stream, d_A, (int)N1, r0, r1, (int)K, g0, g1, (int)O1, P_out, d_src_row,
                        d_src_lo, d_src_hi, d_graph, Dp_out, d_out);

@@ -798,7 +798,7 @@ TSR_API int tsr_corpus_part_features(tsr_ctx *ctx, const tsr_parts *parts, const
         std::vector<uint8_t> none;
         TSR_TRY(tsr_corpus_create_empty(ctx, ooff.data(), N, O1 * K, &cp));
     }
-    void *dA = nullptr, *dRow = nullptr, *dG = nullptr;
+    void *dA = nullptr, *dRow = nullptr, *dG = nullptr, *dGm = nullptr;
     int s = tsr_scratch(ctx, SLOT_AUX, (size_t)std::max<int64_t>(edges->P * N1, 1) * 4, &dA);
     if (s == TSR_OK) s = tsr_scratch(ctx, SLOT_W, (size_t)std::max<int64_t>(P_out, 1) * 12, &dRow);
     int32_t *d_src_row = (int32_t *)dRow, *d_src_lo = d_src_row + P_out, *d_src_hi = d_src_lo + P_out;
@@ -808,9 +808,19 @@ TSR_API int tsr_corpus_part_features(tsr_ctx *ctx, const tsr_parts *parts, const
             hipMemcpyAsync(d_src_hi, src_hi.data(), (size_t)P_out * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
             s = TSR_ERR_HIP;
     }
+    std::vector<uint64_t> gmasks;  // graph rows as part masks (K <= 64), behind the K*K bytes
     if (s == TSR_OK && graph) {
-        s = tsr_scratch(ctx, SLOT_AUX2, (size_t)(K * K), &dG);
-        if (s == TSR_OK && hipMemcpyAsync(dG, graph, (size_t)(K * K), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
+        gmasks.assign((size_t)K, 0);
+        if (K <= 64)
+            for (int64_t a = 0; a < K; ++a)
+                for (int64_t b = 0; b < K; ++b)
+                    if (graph[a * K + b]) gmasks[(size_t)a] |= 1ull << b;
+        const size_t goff = (size_t)((K * K + 15) / 16 * 16);
+        s = tsr_scratch(ctx, SLOT_AUX2, goff + (size_t)K * 8, &dG);
+        if (s == TSR_OK && (hipMemcpyAsync(dG, graph, (size_t)(K * K), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                            hipMemcpyAsync((uint8_t *)dG + goff, gmasks.data(), (size_t)K * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess))
+            s = TSR_ERR_HIP;
+        dGm = (uint8_t *)dG + goff;
     }
     // part ids: the MFMA coder when the tables fit it, else (or on request) the VALU kernel
     bool used_mfma = false;
@@ -837,12 +847,9 @@ TSR_API int tsr_corpus_part_features(tsr_ctx *ctx, const tsr_parts *parts, const
             s = sm;
         }
     }
-    if (s == TSR_OK && P_out > 0) {
-        if (hipMemsetAsync(cp->d_feats, 0, (size_t)P_out * cp->Dp, ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
-        if (s == TSR_OK)
-            s = tsr_launch_spread_stream(ctx, (const int32_t *)dA, N1, r0, r1, K, g0, g1, O1, P_out, d_src_row,
-                                         d_src_lo, d_src_hi, (const uint8_t *)dG, cp->Dp, cp->d_feats);
-    }
+    if (s == TSR_OK && P_out > 0)
+        s = tsr_launch_spread_stream(ctx, (const int32_t *)dA, N1, r0, r1, K, g0, g1, O1, P_out, d_src_row,
+                                     d_src_lo, d_src_hi, (const uint8_t *)dG, (const uint64_t *)dGm, cp->Dp, cp->d_feats);
     int work_host[2] = {0, -1};
     if (s == TSR_OK && used_mfma &&
         hipMemcpyAsync(work_host, dWork, sizeof(work_host), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)

@@ -167,4 +167,4 @@ int tsr_launch_code_parts_stream(tsr_ctx *ctx, const tsr_parts *parts, const uin
 int tsr_launch_spread_stream(tsr_ctx *ctx, const int32_t *d_A, int64_t N1, int r0, int r1, int64_t K,
                              int g0, int g1, int64_t O1, int64_t P_out, const int32_t *d_src_row,
                              const int32_t *d_src_lo, const int32_t *d_src_hi, const uint8_t *d_graph,
-                             int Dp_out, uint8_t *d_out);
+                             const uint64_t *d_graph_masks, int Dp_out, uint8_t *d_out);
