@@ -67,7 +67,7 @@ struct PmArgs {
     int n_inv;                 // empty part slots (incl. the row of ones)
     int *work;                 // [0] chunk counter, [1] list length
     int32_t *argmax;           // [P][N1]
-    uint32_t *list;            // [n][4]: location, full, mask lo, mask hi
+    uint32_t *list;            // [n][2]: location, full (slot 0 of code_parts_fast in play)
 };
 
 __device__ __forceinline__ int med3(int a, int b, int c)
@@ -130,44 +130,45 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
         for (int tile = wave; tile < ntiles; tile += kWaves) {
             const int lp = tile * 32 + n;  // local position of this lane's location
             const uint8_t *xa = rows + lp * 8;
-            // One M-tile (32 part slots) at a time, so that only two limb accumulators are live;
-            // the B fragments are re-read from LDS for the second tile (cheap next to 16 MFMAs).
-            // `visit(mt, r, key)` sees the packed key (I << 6 | slot) of each of this lane's slots.
-            int cnt_own = 0;
-            auto tile_pass = [&](auto &&visit) {
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    i32x16 acc[2] = {};
-#pragma unroll
-                    for (int kb = 0; kb < NKB; ++kb) {
-                        const i32x2 b0 = *reinterpret_cast<const i32x2 *>(xa + boff[kb]);
-                        const i32x2 b1 = *reinterpret_cast<const i32x2 *>(xa + boff[kb] + 8);
-                        const i32x4 b = {b0.x, b0.y, b1.x, b1.y};
-#pragma unroll
-                        for (int l = 0; l < 2; ++l)
-                            acc[l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(W[mt][kb][l], b, acc[l], 0, 0, 0);
-                    }
-                    // keep the two M-tiles apart in the schedule (one accumulator pair live: the
-                    // weights leave no room for two); the SIMD's other wave fills the gaps
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        const i32x4 kc = *reinterpret_cast<const i32x4 *>(kcl + (half * 2 + mt) * 16 + r4 * 4);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            visit(mt, r4 * 4 + c, (acc[1][r4 * 4 + c] << 14) + (acc[0][r4 * 4 + c] << 6) + kc[c]);
-                    }
-                    if (mt == 1) cnt_own = acc[0][15];  // the row of ones is slot 63: half 1, mt 1, r 15
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            };
-            int best = INT32_MIN, second = INT32_MIN;
+            // One M-tile (32 part slots) at a time, so that only two limb accumulators are live; the
+            // B fragments of a pass are all requested up front (one LDS latency per pass) and read
+            // again for the second M-tile (cheap next to 16 MFMAs).  Each of this lane's 32 slots
+            // yields a packed key (I << 6 | slot); best and second best are tracked per lane.
+            int best = INT32_MIN, second = INT32_MIN, cnt_own = 0;
             float vsum = 0.0f;
-            tile_pass([&](int, int, int key) {
-                second = med3(best, second, key);
-                best = max(best, key);
-                if (a.fast) vsum += (float)(key >> 6);
-            });
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                i32x16 acc[2] = {};
+                i32x4 bf[NKB];
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
+                    const i32x2 b0 = *reinterpret_cast<const i32x2 *>(xa + boff[kb]);
+                    const i32x2 b1 = *reinterpret_cast<const i32x2 *>(xa + boff[kb] + 8);
+                    bf[kb] = (i32x4){b0.x, b0.y, b1.x, b1.y};
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int l = 0; l < 2; ++l)
+                        acc[l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(W[mt][kb][l], bf[kb], acc[l], 0, 0, 0);
+                // keep the two M-tiles apart in the schedule (one accumulator pair live: the weights
+                // leave no room for two); the SIMD's other wave fills the gaps
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const i32x4 kc = *reinterpret_cast<const i32x4 *>(kcl + (half * 2 + mt) * 16 + r4 * 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int key = (acc[1][r4 * 4 + c] << 14) + (acc[0][r4 * 4 + c] << 6) + kc[c];
+                        second = med3(best, second, key);
+                        best = max(best, key);
+                        if (a.fast) vsum += (float)(key >> 6);
+                    }
+                }
+                if (mt == 1) cnt_own = acc[0][15];  // the row of ones is slot 63: half 1, mt 1, r 15
+                __builtin_amdgcn_sched_barrier(0);
+            }
             const int obest = __shfl_xor(best, 32), osecond = __shfl_xor(second, 32);
             const unsigned count = (unsigned)__shfl(cnt_own, n + 32);
             const int mbest = max(best, obest);
@@ -198,95 +199,90 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
                 flag = flag || full;
             }
             const int64_t loc = f * a.N1 + j;
-            if (__builtin_amdgcn_ballot_w64(flag) != 0) {
-                // rare (a few percent of the tiles): some location needs the f64 re-evaluation.  Run
-                // the tile again to collect, per location, the parts inside the window.
-                const int thr = vbest - window;
-                unsigned mlo = 0, mhi = 0;
-                tile_pass([&](int mt, int r, int key) {
-                    const unsigned bit = ((key >> 6) >= thr) ? (1u << (8 * (r >> 2) + half * 4 + (r & 3))) : 0u;
-                    if (mt == 0)
-                        mlo |= bit;
-                    else
-                        mhi |= bit;
-                });
-                mlo |= __shfl_xor(mlo, 32);
-                mhi |= __shfl_xor(mhi, 32);
-                if (flag && half == 0) {
-                    const int slot = atomicAdd(a.work + 1, 1);
-                    uint32_t *e = a.list + (size_t)slot * 4;
-                    e[0] = (uint32_t)loc;
-                    e[1] = full ? 1u : 0u;
-                    e[2] = mlo;
-                    e[3] = mhi;
-                }
+            if (flag && half == 0) {  // rare: hand the location to the f64 re-evaluation
+                const int slot = atomicAdd(a.work + 1, 1);
+                a.list[(size_t)slot * 2] = (uint32_t)loc;
+                a.list[(size_t)slot * 2 + 1] = full ? 1u : 0u;
             }
             if (live && half == 0 && !flag) a.argmax[loc] = coded ? (mbest & 63) + 1 : 0;
         }
     }
 }
 
-// The reference's sequential f64 sums for the listed locations, restricted to the parts inside
-// the window (all parts, and slot 0, for `full` entries).  One lane per entry: the sum over the
-// patch cells is sequential by definition, so the parallelism is across entries.  The lane first
-// packs its patch into bit words (LDS, one column per lane) so that the table reads no longer
-// depend on a byte load each, then walks tab_kq [k][q][2] (one part = one contiguous 16*Q-byte
-// run: every cache line serves 8 cells) with 16 loads in flight.
-constexpr int kRcThreads = 128;
-constexpr int kRcWords = 8;  // Q <= 256 cells (16 K-groups of 16)
+// The reference's sequential f64 sums for the listed locations.  One wave takes kRcEnt entries
+// at a time, one lane per part: the lane reads both table values of a cell once ([q][k][2], a
+// coalesced 16 bytes per lane) and adds the one each entry's edge bit selects to that entry's
+// accumulator, in the reference's cell order (i -> j -> z) -- every sum is the reference's bit
+// for bit, and the table is streamed once per kRcEnt entries instead of once per entry.  The
+// first maximum over the lanes is np.argmax's; for `full` entries slot 0 of code_parts_fast,
+// sum_k (S_k - 1) in ascending k (code_parts.pyx:289-293), decides between it and index 0.
+constexpr int kRcWaves = 4;
+constexpr int kRcEnt = 4;
+constexpr int kRcBins = 32;  // P0 * P1 <= 2 * (16 K-groups)
 
-__global__ __launch_bounds__(kRcThreads) void code_parts_recheck_kernel(
-    const uint8_t *__restrict__ X, int Dp, int E, int P0, int P1, int N1, const double *__restrict__ tab_kq /*[K][Q][2]*/,
+__global__ __launch_bounds__(64 * kRcWaves) void code_parts_recheck_kernel(
+    const uint8_t *__restrict__ X, int Dp, int P0, int P1, int N1, const double *__restrict__ tab /*[Q][K][2]*/,
     int K, int fast, const uint32_t *__restrict__ list, const int *__restrict__ work, int32_t *__restrict__ argmax)
 {
-    __shared__ uint32_t xw[kRcWords][kRcThreads];
+    static_assert(kRcEnt == 4, "the bin word below holds 4 entries");
+    __shared__ __attribute__((aligned(4))) uint8_t xbits[kRcWaves][kRcBins][kRcEnt];  // one byte = the 8 edge bits of one bin of one entry's patch
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = work[1];
-    const int Q = P0 * P1 * E, rowc = P1 * E;
-    for (int e = blockIdx.x * kRcThreads + threadIdx.x; e < n; e += gridDim.x * kRcThreads) {
-        const uint32_t loc = list[(size_t)e * 4];
-        const bool full = list[(size_t)e * 4 + 1] != 0;
-        uint64_t mask = ((uint64_t)list[(size_t)e * 4 + 3] << 32) | list[(size_t)e * 4 + 2];
-        if (full) mask = ~0ull;
-        const int i0 = (int)(loc / (unsigned)N1), j0 = (int)(loc - (unsigned)i0 * (unsigned)N1);
-        const uint8_t *x0 = X + (int64_t)i0 * Dp + j0 * E;
-        for (int w = 0; w < kRcWords; ++w) xw[w][threadIdx.x] = 0;
-        for (int i = 0; i < P0; ++i)
-            for (int j = 0; j < P1; ++j) {  // E == 8: one bin = one aligned 8-byte word of 0/1 bytes -> 8 bits
-                const uint64_t v = *reinterpret_cast<const uint64_t *>(x0 + (int64_t)i * Dp + j * 8);
-                const uint32_t b8 = (uint32_t)((v * 0x0102040810204080ull) >> 56);
-                const int q = (i * P1 + j) * 8;
-                xw[q >> 5][threadIdx.x] |= b8 << (q & 31);
-            }
-        int bestk = -1;
-        double bestv = 0.0, slot0 = 0.0;
-        if (K < 64) mask &= (1ull << K) - 1;
-        while (mask) {  // every lane walks ITS OWN candidates (ascending k), not the wave's union
-            const int k = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const double *t = tab_kq + (int64_t)k * Q * 2;
-            double acc = 0.0;
-            for (int w = 0; w * 32 < Q; ++w) {
-                const uint32_t bits = xw[w][threadIdx.x];
-                const int nb = min(32, Q - w * 32);
-                int b = 0;
-                for (; b + 16 <= nb; b += 16) {
-                    double v[16];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) v[u] = t[(w * 32 + b + u) * 2 + ((bits >> (b + u)) & 1)];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) acc += v[u];
-                }
-                for (; b < nb; ++b) acc += t[(w * 32 + b) * 2 + ((bits >> b) & 1)];
-            }
-            slot0 += acc - 1.0;
-            if (bestk < 0 || acc > bestv) {
-                bestv = acc;
-                bestk = k;
-            }
+    const int nbins = P0 * P1;
+    const int kl = min(lane, K - 1);  // idle lanes shadow the last part (their sums are ignored)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 *t2 = reinterpret_cast<const d2 *>(tab) + kl;
+    for (int e0 = (blockIdx.x * kRcWaves + wave) * kRcEnt; e0 < n; e0 += gridDim.x * kRcWaves * kRcEnt) {
+        for (int idx = lane; idx < nbins * kRcEnt; idx += 64) {  // E == 8: one bin = one aligned 8-byte word of 0/1 bytes
+            const int b = idx / kRcEnt, e = idx - b * kRcEnt;
+            const uint32_t loc = list[(size_t)min(e0 + e, n - 1) * 2];
+            const int i0 = (int)(loc / (unsigned)N1), j0 = (int)(loc - (unsigned)i0 * (unsigned)N1);
+            const int i = b / P1, j = b - i * P1;
+            const uint64_t v = *reinterpret_cast<const uint64_t *>(X + (int64_t)(i0 + i) * Dp + (j0 + j) * 8);
+            xbits[wave][b][e] = (uint8_t)((v * 0x0102040810204080ull) >> 56);
         }
-        int res = bestk + 1;
-        if (full && fast && !(bestv > slot0)) res = 0;
-        argmax[loc] = res;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double acc[kRcEnt];
+#pragma unroll
+        for (int e = 0; e < kRcEnt; ++e) acc[e] = 0.0;
+        for (int b = 0; b < nbins; ++b) {
+            const uint32_t bw = *reinterpret_cast<const uint32_t *>(&xbits[wave][b][0]);  // the bin's bits of the 4 entries
+            d2 tv[8];
+#pragma unroll
+            for (int z = 0; z < 8; ++z) tv[z] = t2[(int64_t)(b * 8 + z) * K];
+#pragma unroll
+            for (int z = 0; z < 8; ++z)
+#pragma unroll
+                for (int e = 0; e < kRcEnt; ++e) {
+                    const unsigned byte = (bw >> (8 * e)) & 0xffu;
+                    acc[e] += ((byte >> z) & 1) ? tv[z].y : tv[z].x;
+                }
+        }
+#pragma unroll
+        for (int e = 0; e < kRcEnt; ++e) {
+            if (e0 + e >= n) break;  // uniform
+            // first maximum over the parts (lanes >= K never win)
+            double bv = acc[e];
+            int bk = lane < K ? lane : 0x7fffffff;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double ov = __shfl_xor(bv, off);
+                const int ok = __shfl_xor(bk, off);
+                const bool take = (ok != 0x7fffffff) && (bk == 0x7fffffff || ov > bv || (ov == bv && ok < bk));
+                bv = take ? ov : bv;
+                bk = take ? ok : bk;
+            }
+            int res = bk + 1;
+            if (fast && list[(size_t)(e0 + e) * 2 + 1] != 0) {
+                double slot0 = 0.0;
+                for (int k = 0; k < K; ++k) slot0 += __shfl(acc[e], k) - 1.0;
+                if (!(bv > slot0)) res = 0;
+            }
+            if (lane == 0) argmax[list[(size_t)(e0 + e) * 2]] = res;
+        }
+        __builtin_amdgcn_wave_barrier();  // xbits is rewritten by the next group
     }
 }
 
@@ -307,8 +303,6 @@ void tsr_parts_mfma_free(tsr_parts *p)
 {
     if (p->d_wq) (void)hipFree(p->d_wq);
     if (p->d_kc) (void)hipFree(p->d_kc);
-    if (p->d_tab_kq) (void)hipFree(p->d_tab_kq);
-    p->d_tab_kq = nullptr;
     p->d_wq = nullptr;
     p->d_kc = nullptr;
     p->mfma_ok = false;
@@ -415,13 +409,6 @@ int tsr_parts_mfma_prepare(tsr_ctx *ctx, tsr_parts *p, const double *lp, const d
     TSR_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_kc), kc.size() * 4));
     TSR_HIP(hipMemcpyAsync(p->d_wq, wq.data(), wq.size(), hipMemcpyHostToDevice, ctx->stream));
     TSR_HIP(hipMemcpyAsync(p->d_kc, kc.data(), kc.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    std::vector<double> tkq((size_t)(K * Q * 2));
-    for (int64_t i = 0; i < K * Q; ++i) {
-        tkq[(size_t)i * 2] = lip[i];
-        tkq[(size_t)i * 2 + 1] = lp[i];
-    }
-    TSR_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_tab_kq), tkq.size() * 8));
-    TSR_HIP(hipMemcpyAsync(p->d_tab_kq, tkq.data(), tkq.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     TSR_HIP(hipStreamSynchronize(ctx->stream));
     p->mfma_ok = true;
     p->mfma_why[0] = 0;
@@ -430,7 +417,7 @@ int tsr_parts_mfma_prepare(tsr_ctx *ctx, tsr_parts *p, const double *lp, const d
 
 // Part ids of every live location of a resident edge stream -> d_argmax [P][N1].
 // Returns TSR_ERR_UNSUPPORTED (nothing enqueued) when this corpus geometry does not fit.
-// d_list must hold 16 bytes per location, d_work two ints.
+// d_list must hold 8 bytes per location, d_work two ints.
 int tsr_launch_code_parts_mfma(tsr_ctx *ctx, const tsr_parts *p, const uint8_t *d_X, int64_t P, int64_t X1,
                                int Dp, const int32_t *d_utt_end, int threshold, int fast, int32_t *d_argmax,
                                uint32_t *d_list, int *d_work)
@@ -488,8 +475,8 @@ int tsr_launch_code_parts_mfma(tsr_ctx *ctx, const tsr_parts *p, const uint8_t *
     default: return TSR_ERR_UNSUPPORTED;
     }
     TSR_TRY(s);
-    hipLaunchKernelGGL(code_parts_recheck_kernel, dim3((unsigned)(8 * std::max(ctx->cus, 1))), dim3(kRcThreads), 0, ctx->stream,
-                       d_X, Dp, (int)p->E, (int)p->P0, (int)p->P1, (int)N1, p->d_tab_kq, (int)p->K, fast ? 1 : 0,
+    hipLaunchKernelGGL(code_parts_recheck_kernel, dim3((unsigned)(8 * std::max(ctx->cus, 1))), dim3(64 * kRcWaves), 0, ctx->stream,
+                       d_X, Dp, (int)p->P0, (int)p->P1, (int)N1, p->d_tab, (int)p->K, fast ? 1 : 0,
                        (const uint32_t *)d_list, (const int *)d_work, d_argmax);
     TSR_HIP(hipGetLastError());
     return TSR_OK;

@@ -829,7 +829,7 @@ TSR_API int tsr_corpus_part_features(tsr_ctx *ctx, const tsr_parts *parts, const
         int sm = TSR_ERR_UNSUPPORTED;
         if (parts->mode != TSR_PARTS_VALU && parts->mfma_ok) {
             void *dList = nullptr;
-            sm = tsr_scratch(ctx, SLOT_LIST, (size_t)std::max<int64_t>(edges->P * N1, 1) * 16, &dList);
+            sm = tsr_scratch(ctx, SLOT_LIST, (size_t)std::max<int64_t>(edges->P * N1, 1) * 8, &dList);
             if (sm == TSR_OK) sm = tsr_scratch(ctx, SLOT_CNT, 64, &dWork);
             if (sm == TSR_OK)
                 sm = tsr_launch_code_parts_mfma(ctx, parts, edges->d_feats, edges->P, X1, edges->Dp, edges->d_utt_end,

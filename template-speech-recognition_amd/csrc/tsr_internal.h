@@ -124,7 +124,6 @@ struct tsr_parts {
     float pm_o0_const = 0, pm_o0_slack = 0;
     void *d_wq = nullptr;     // int8 [mt 2][kb][limb 2][lane 64][16]
     int32_t *d_kc = nullptr;  // [half 2][mt 2][16]: (base sum << 6) | part
-    double *d_tab_kq = nullptr;  // [k][q][2] = {log_invparts, log_parts}: the re-evaluation's table
     int64_t last_locations = 0, last_rechecked = -1;  // of the latest tsr_corpus_part_features (-1: VALU kernel ran)
 };
 

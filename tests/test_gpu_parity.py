@@ -405,3 +405,45 @@ def test_part_coder_mfma_unsupported_falls_back(mods, oracle):
     parts.set_mode(tsr_hip.TSR_PARTS_MFMA)
     with pytest.raises(tsr_hip.TsrError):
         corpus.part_features(parts, 10, spread=(1, 1))
+
+
+def test_config3_fullsize_coders_agree(mods, oracle):
+    """BASELINE config 3 at full size (1000 x 200 frames x 45 bins x 8 edges, 50 parts): the MFMA
+    coder and the f64 VALU kernel produce the same part corpus byte for byte; a sample of
+    utterances is checked against the oracle chain; the D=2050 bank scores it in both precisions."""
+    tsr_hip = mods[3]
+    from tsr_hip import synth
+    rng = np.random.default_rng(3)
+    N, T, F, K = 1000, 200, 45, 50
+    q = synth.background(rng, (F, 8))
+    feats = (rng.random((N * T, F, 8)) < q).astype(np.uint8)
+    offs = np.arange(N + 1, dtype=np.int64) * T
+    lp, lip = synth.parts(rng, K)
+    corpus = tsr_hip.Corpus(feats.reshape(N * T, -1), offs)
+    parts = tsr_hip.Parts(lp, lip)
+    out = {}
+    for mode in (tsr_hip.TSR_PARTS_MFMA, tsr_hip.TSR_PARTS_VALU):
+        parts.set_mode(mode)
+        pc = corpus.part_features(parts, 12, spread=(2, 2))
+        out[mode] = pc.download_feats()
+        if mode == tsr_hip.TSR_PARTS_MFMA:
+            info = parts.info()
+            assert info["locations"] == N * T * (F - 4)
+            assert 0 <= info["rechecked"] < info["locations"] // 50     # the f64 path stays the exception
+            pc_mfma = pc
+    assert np.array_equal(out[tsr_hip.TSR_PARTS_MFMA], out[tsr_hip.TSR_PARTS_VALU])
+    got = out[tsr_hip.TSR_PARTS_MFMA].reshape(N, T - 4, (F - 4) * K)
+    for n in rng.choice(N, size=3, replace=False):
+        want = _oracle_part_chain(oracle, [feats[offs[n]:offs[n + 1]]], lp, lip, 12, (2, 2), (1, 1), False, K)[0]
+        assert np.array_equal(got[n], want.reshape(T - 4, -1))
+    bank_cs = synth.bank(rng, synth.background(rng, (F - 4, K)), [32] * 8)
+    bank = tsr_hip.Bank(bank_cs)
+    pc_mfma.score(bank, tsr_hip.TSR_EXACT)
+    se, ae = pc_mfma.download()
+    pc_mfma.score(bank, tsr_hip.TSR_FAST)
+    sf, af = pc_mfma.download()
+    assert rel_err(sf, se) <= TOL
+    n0 = int(rng.integers(N))
+    so, ao = oracle.score_bank(got[n0], bank_cs)
+    sl = slice(pc_mfma.offsets[n0], pc_mfma.offsets[n0 + 1])
+    assert np.array_equal(se[sl], so) and np.array_equal(ae[sl], ao)
