@@ -74,6 +74,48 @@ def cpu_baseline(corpus, budget_s=12.0):
                       % (n, len(offs) - 1, frames, dt)}
 
 
+def extras(ctx, corpus, bank, flags):
+    """Secondary numbers: the host-buffer boundary including PCIe, and config 3."""
+    frames = int(corpus["offsets"][-1])
+    best = None
+    for _ in range(3):  # upload + score + download through the host-pointer entry points
+        ctx.sync()
+        t0 = time.perf_counter()
+        c = tsr_hip.Corpus(corpus["feats"], corpus["offsets"], ctx=ctx)
+        c.score(bank, flags)
+        c.download()
+        dt = time.perf_counter() - t0
+        c.close()
+        best = dt if best is None else min(best, dt)
+    res = {"pcie_inclusive": {"frames_per_s": frames / best, "ms": best * 1e3,
+                              "what": "tsr_corpus_create (pageable host -> HBM) + score + tsr_corpus_download, best of 3"}}
+    # config 3: same N, T; raw edge maps -> code_parts(K=50, thr=12) -> argmax -> spread(2,2) -> D=2050 bank
+    rng = np.random.default_rng(3)
+    lp, lip = synth.parts(rng, 50)
+    parts = tsr_hip.Parts(lp, lip, ctx=ctx)
+    bank3 = tsr_hip.Bank(synth.bank(rng, synth.background(rng, (CFG["F"] - 4, 50)), [CFG["L"]] * CFG["M"]), ctx=ctx)
+    edges = tsr_hip.Corpus(corpus["feats"], corpus["offsets"], ctx=ctx)
+    fe_ms, bank_ms = [], []
+    for _ in range(4):
+        ctx.sync()
+        t0 = time.perf_counter()
+        pc = edges.part_features(parts, 12, spread=(2, 2))   # synchronous: returns the new corpus
+        fe_ms.append((time.perf_counter() - t0) * 1e3)
+        pc.score(bank3, flags)
+        ctx.sync()
+        ctx.timer_start()
+        pc.score(bank3, flags)
+        bank_ms.append(ctx.timer_stop())
+        pc.close()
+    info = parts.info()
+    res["config3"] = {"front_end_wall_ms": min(fe_ms[1:]), "bank_D2050_kernel_ms": min(bank_ms[1:]),
+                      "frames_per_s": frames / ((min(fe_ms[1:]) + min(bank_ms[1:])) * 1e-3),
+                      "patch_locations": info["locations"], "f64_rechecked": info["rechecked"],
+                      "what": "code_parts(K=50,thr=12) -> argmax -> spread(2,2) -> 8x32-tap bank on D=2050; "
+                              "front-end wall time includes the hipMalloc of the 404 MB part corpus"}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +126,9 @@ def main():
                     help="fast: MFMA, 16-bit fixed-point weights (2 int8 limbs); fast24: 23-bit "
                          "(3 limbs); exact: f32 VALU in the reference's summation order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extras", action="store_true",
+                    help="N=1 only: add the PCIe-inclusive rate and BASELINE config 3 (parts front-end + "
+                         "D=2050 bank) to the JSON line under \"extras\" (never part of `value`)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -198,6 +243,10 @@ def main():
                        "mode": args.mode, "frames_per_gpu": frames, "parallelism": "utterance-sharded x%d" % world},
             "roofline": roofline,
         }
+        out["config"]["window_templates_per_s"] = (CFG["N"] * CFG["M"] * (CFG["T"] - CFG["L"] + 1)
+                                                   * world * args.steps / wall)
+        if world == 1 and args.extras:
+            out["extras"] = extras(ctx, corpus, bank, flags)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(corpus)
         print(json.dumps(out))
