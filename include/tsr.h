@@ -176,6 +176,27 @@ int tsr_parts_info(const tsr_parts *parts, int *mfma_available, int64_t *locatio
 int tsr_corpus_download_feats(tsr_ctx *ctx, const tsr_corpus *corpus, uint8_t *feats);
 int tsr_corpus_shape(const tsr_corpus *corpus, int64_t *N, int64_t *D, int64_t *frame_offsets);
 
+/* ---- phone-window classification on top of the scores ----------- */
+/* _compute_classification_E (get_train_data.py:718-773) over a resident corpus.  Window w is the
+ * frame range [starts[w], ends[w]) of the stream (get_classify_windows :710-716 shifted by the
+ * utterance's first frame); it must be non-empty and lie inside one utterance.  Per template the
+ * FIRST maximum of detect(E, W_m) + c_m over the window (np.argmax), across templates the highest
+ * value, the earlier template on ties (strict '<' at :768).  score f32 [W], loc i64 [W] (stream frame
+ * of the maximum), template_id i32 [W].  Locations equal the reference's with TSR_EXACT; with
+ * TSR_FAST the scores carry the 16-bit weight quantisation and a near-tie may resolve differently. */
+int tsr_corpus_classify_windows(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *corpus,
+                                const int64_t *starts, const int64_t *ends, int64_t W, int flags,
+                                float *score, int64_t *loc, int32_t *template_id);
+/* _compute_isolated_classification_E (get_train_data.py:838-925): W background-padded f32 windows
+ * (built by get_isolated_classify_windows :781-835), rows concatenated in E_cat f32 [R, D], window w =
+ * rows [row_offsets[w], row_offsets[w+1]); every template is run with detect_float's arithmetic
+ * (compute_likelihood_linear_filter.pyx:178-219: f32, product rounded before the add) + f32(c_m), the
+ * arg-max covers the first n_valid[w] positions of the window.  loc i32 [W] is the position inside
+ * the window.  Bit-identical scores, hence identical locations and template ids. */
+int tsr_classify_float_windows(tsr_ctx *ctx, const tsr_bank *bank, const float *E_cat,
+                               const int64_t *row_offsets, const int32_t *n_valid, int64_t W,
+                               float *score, int32_t *loc, int32_t *template_id);
+
 /* ---- multi-GPU: utterances shard across ranks, the bank is broadcast once ----- */
 /* One process per GPU.  Rank 0 calls tsr_dist_unique_id and hands the 128 bytes
  * to the other ranks over any host channel; every rank then calls

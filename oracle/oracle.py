@@ -293,3 +293,83 @@ def compute_detection_E(E, linear_filters_cs):
         ids[v > row] = m
         row = np.maximum(v, row)
     return row.astype(np.float32), ids
+
+
+# ---- classification over phone windows, restated from text --------------------
+# The callers below are Python-2 modules that cannot be imported; they are restated line for line
+# with the NumPy-1.x promotion (f32 array + f64 scalar -> f32) made explicit.  `_detect` /
+# `_detect_float` default to this oracle's C restatements and are swapped for the compiled
+# reference's functions when the golden vectors are generated.
+def get_classify_windows(phns, flts):
+    """get_train_data.py:710-716."""
+    flts = np.asarray(flts)
+    window_starts = np.maximum(0, flts[:-1] + (flts[:-1] - flts[1:]) / 3.).astype(np.int16)
+    window_ends = np.minimum(flts[-1], flts[:-1] + (flts[1:] - flts[:-1]) / 3.).astype(np.int16)
+    return window_starts, window_ends
+
+
+def compute_classification_E(E, phns, E_flts, utt_id, classify_array, classify_template_ids,
+                             classify_template_lengths, classify_locs, linear_filters_cs,
+                             _detect=None):
+    """get_train_data.py:718-773 (_compute_classification_E): per phone window the first maximum
+    of detect + c per template, then the best template (strict '<': the earlier one on ties)."""
+    _detect = _detect or detect
+    window_starts, window_ends = get_classify_windows(phns, E_flts)
+    E8 = np.asarray(E).astype(np.uint8)
+    for filter_id, (cur_filt, cur_c) in enumerate(linear_filters_cs):
+        detection_scores = _detect(E8, cur_filt) + np.float32(cur_c)
+        for phn_id, (w_start, w_end) in enumerate(zip(window_starts, window_ends)):
+            w_start, w_end = int(w_start), int(w_end)
+            t = w_start + int(np.argmax(detection_scores[w_start:w_end]))
+            if filter_id == 0 or classify_array[utt_id, phn_id] < detection_scores[t]:
+                classify_locs[utt_id, phn_id] = t
+                classify_template_ids[utt_id, phn_id] = filter_id
+                classify_template_lengths[utt_id, phn_id] = len(cur_filt)
+                classify_array[utt_id, phn_id] = detection_scores[t]
+
+
+def get_isolated_classify_windows(E, phns, flts, bgd, linear_filters_cs, max_length=None):
+    """get_train_data.py:781-835.  NOTE: like the reference, shifts `flts` IN PLACE by the front
+    padding.  Returns (E_windows, window_starts, window_ends, flts[0])."""
+    if max_length is None:
+        max_filter_length = max(len(lfc[0]) for lfc in linear_filters_cs)
+    else:
+        max_filter_length = max_length
+    max_phn_length_third = int(np.ceil(np.max(flts[1:] - flts[:-1]) / 3.))
+    ones = (1,) * len(bgd.shape)
+    E = np.vstack((
+        np.tile(bgd, (max_filter_length + max_phn_length_third,) + ones).astype(np.float32),
+        E.astype(np.float32),
+        np.tile(bgd, (max(0, int(flts[-2]) + max_phn_length_third + max_filter_length - int(flts[-1])),)
+                + ones).astype(np.float32)))
+    flts += max_filter_length + max_phn_length_third
+    window_starts = (flts[:-1] + (flts[:-1] - flts[1:]) / 3.).astype(np.int16)
+    window_ends = (flts[:-1] + (flts[1:] - flts[:-1]) / 3.).astype(np.int16)
+    phn_segment_ends = (flts[1:] + (flts[1:] - flts[:-1]) / 3.).astype(np.int16)
+    E_windows = tuple(
+        np.vstack((E[int(ws):int(pse)].astype(np.float32),
+                   np.tile(bgd, (max(0, int(we) + max_filter_length - int(pse)),) + ones)))
+        for ws, we, pse in zip(window_starts, window_ends, phn_segment_ends))
+    return E_windows, window_starts, window_ends, flts[0]
+
+
+def compute_isolated_classification_E(E, phns, E_flts, utt_id, classify_array, classify_template_ids,
+                                      classify_template_lengths, classify_locs, linear_filters_cs, bgd,
+                                      _detect_float=None):
+    """get_train_data.py:838-925 without the optional SVM stage: every phone gets its own
+    background-padded f32 window, scored with detect_float (detect_float2d for 2-d features) + c;
+    the arg-max runs over the first w_end - w_start positions only."""
+    _detect_float = _detect_float or detect_float
+    E_windows, window_starts, window_ends, flt_front_pad = get_isolated_classify_windows(
+        E, phns, E_flts, bgd, linear_filters_cs)
+    for phn_id, (E_window, w_start, w_end) in enumerate(zip(E_windows, window_starts, window_ends)):
+        w_start, w_end = int(w_start), int(w_end)
+        for filter_id, (cur_filt, cur_c) in enumerate(linear_filters_cs):
+            detection_scores = _detect_float(E_window, cur_filt) + np.float32(cur_c)
+            t = w_start + int(np.argmax(detection_scores[:w_end - w_start])) - int(flt_front_pad)
+            v = detection_scores[t - w_start + int(flt_front_pad)]
+            if filter_id == 0 or classify_array[utt_id, phn_id] < v:
+                classify_locs[utt_id, phn_id] = t
+                classify_template_ids[utt_id, phn_id] = filter_id
+                classify_template_lengths[utt_id, phn_id] = len(cur_filt)
+                classify_array[utt_id, phn_id] = v

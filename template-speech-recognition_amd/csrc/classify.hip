@@ -1,0 +1,158 @@
+// classify.hip -- phone-window classification on top of the template scores:
+//   _compute_classification_E            get_train_data.py:718-773
+//   _compute_isolated_classification_E   get_train_data.py:838-925
+//
+// Both reduce, for every phone window, the per-template score rows detect*(E, W_m) + c_m to one
+// triple (score, location, template):  per template the FIRST maximum inside the window
+// (np.argmax), across templates the highest value with the EARLIER template on ties (strict '<',
+// :768 / :907).  `window_argmax_kernel` does that reduction for both variants; the isolated
+// variant's scores come from `float_windows_kernel`, detect_float's arithmetic (f32, product
+// rounded before the add, taps in the order tau -> d) on the listed positions of the
+// background-padded f32 windows only.
+#include "tsr_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// One wave per window.  all: f32 [M][stride] score rows; window w covers columns
+// [starts[w], ends[w]).  Lane-level: strict '>' while walking t upwards keeps the first maximum;
+// wave-level: higher value, then lower t.  Across templates: strict '<' keeps the earlier one.
+__global__ __launch_bounds__(kThreads) void window_argmax_kernel(
+    const float *__restrict__ all, int64_t stride, int M, const int64_t *__restrict__ starts,
+    const int64_t *__restrict__ ends, int64_t W, float *__restrict__ score, int64_t *__restrict__ loc,
+    int32_t *__restrict__ tid)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (w >= W) return;
+    const int64_t s = starts[w], e = ends[w];
+    float best = 0.0f;
+    int64_t best_t = s;
+    int best_m = 0;
+    for (int m = 0; m < M; ++m) {
+        const float *row = all + (int64_t)m * stride;
+        bool have = false;
+        float v = 0.0f;
+        int64_t vt = 0;
+        for (int64_t t = s + lane; t < e; t += 64) {
+            const float x = row[t];
+            if (!have || x > v) {
+                v = x;
+                vt = t;
+                have = true;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(v, off);
+            const int64_t ot = __shfl_xor(vt, off);
+            const bool oh = __shfl_xor((int)have, off) != 0;
+            const bool take = oh && (!have || ov > v || (ov == v && ot < vt));
+            v = take ? ov : v;
+            vt = take ? ot : vt;
+            have = have || oh;
+        }
+        if (m == 0 || best < v) {
+            best = v;
+            best_t = vt;
+            best_m = m;
+        }
+    }
+    if (lane == 0) {
+        score[w] = best;
+        loc[w] = best_t;
+        tid[w] = best_m;
+    }
+}
+
+// detect_float on listed positions.  One lane per position i, TSR_MG templates per lane (group
+// blockIdx.y): out[m][i] = (L_m <= rows_left[i] ? sum_{tau<L_m} sum_d X[row[i]+tau][d]*W_m[tau][d] : 0)
+// + f32(c_m), the sum sequential in f32 with the product rounded first
+// (compute_likelihood_linear_filter.pyx:178-219: no fused multiply-add).  Weights arrive as
+// wave-uniform scalar loads from the exact path's layout Wx[g][tau][d][m%8] (zero beyond L_m, so
+// the shorter templates of a group simply add +0).
+template <bool VEC4>
+__global__ __launch_bounds__(kThreads) void float_windows_kernel(
+    const float *__restrict__ X, int D, int WR32, const int32_t *__restrict__ item_row,
+    const int32_t *__restrict__ item_left, int64_t NW, const float *__restrict__ Wx,
+    const int64_t *__restrict__ gx_off, const int32_t *__restrict__ gx_L, const int32_t *__restrict__ Lm,
+    const float *__restrict__ cf, int M, float *__restrict__ out)
+{
+#pragma clang fp contract(off)  // the reference rounds the product to f32 before the add
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int g = blockIdx.y;
+    const bool on = i < NW;
+    const int row = on ? item_row[i] : 0;
+    const int left = on ? item_left[i] : 0;
+    const float *__restrict__ wg = Wx + gx_off[g];
+    const int Lg = gx_L[g];
+    float acc[TSR_MG];
+#pragma unroll
+    for (int j = 0; j < TSR_MG; ++j) acc[j] = 0.0f;
+    for (int tau = 0; tau < Lg; ++tau) {
+        const bool have = tau < left;  // rows beyond the window: weights of the templates that reach here are 0
+        const float *__restrict__ x = X + (int64_t)(row + (have ? tau : 0)) * D;
+        const float *__restrict__ wt = wg + (int64_t)tau * WR32 * TSR_MG;
+        if (VEC4) {
+            for (int d = 0; d < D; d += 4) {
+                float4 xv = *reinterpret_cast<const float4 *>(x + d);
+                if (!have) xv = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < TSR_MG; ++j) {
+                        const float prod = wt[(d + u) * TSR_MG + j] * xs[u];
+                        acc[j] = acc[j] + prod;
+                    }
+            }
+        } else {
+            for (int d = 0; d < D; ++d) {
+                const float xv = have ? x[d] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < TSR_MG; ++j) {
+                    const float prod = wt[d * TSR_MG + j] * xv;
+                    acc[j] = acc[j] + prod;
+                }
+            }
+        }
+    }
+    if (!on) return;
+#pragma unroll
+    for (int j = 0; j < TSR_MG; ++j) {
+        const int m = g * TSR_MG + j;
+        if (m < M) out[(int64_t)m * NW + i] = (Lm[m] <= left ? acc[j] : 0.0f) + cf[m];
+    }
+}
+
+}  // namespace
+
+int tsr_launch_window_argmax(tsr_ctx *ctx, const float *d_all, int64_t stride, int M, const int64_t *d_starts,
+                             const int64_t *d_ends, int64_t W, float *d_score, int64_t *d_loc, int32_t *d_tid)
+{
+    if (W <= 0) return TSR_OK;
+    const int wpb = kThreads / 64;
+    hipLaunchKernelGGL(window_argmax_kernel, dim3((unsigned)((W + wpb - 1) / wpb)), dim3(kThreads), 0, ctx->stream,
+                       d_all, stride, M, d_starts, d_ends, W, d_score, d_loc, d_tid);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+
+int tsr_launch_float_windows(tsr_ctx *ctx, const tsr_bank *bank, const float *d_X, const int32_t *d_item_row,
+                             const int32_t *d_item_left, int64_t NW, float *d_out)
+{
+    if (NW <= 0) return TSR_OK;
+    const int D = (int)bank->D;
+    dim3 grid((unsigned)((NW + kThreads - 1) / kThreads), (unsigned)bank->n_groups);
+    if (D % 4 == 0)
+        hipLaunchKernelGGL(float_windows_kernel<true>, grid, dim3(kThreads), 0, ctx->stream, d_X, D, bank->Dq * 32,
+                           d_item_row, d_item_left, NW, bank->d_Wx, bank->d_gx_off, bank->d_gx_L, bank->d_L,
+                           bank->d_cf, (int)bank->M, d_out);
+    else
+        hipLaunchKernelGGL(float_windows_kernel<false>, grid, dim3(kThreads), 0, ctx->stream, d_X, D, bank->Dq * 32,
+                           d_item_row, d_item_left, NW, bank->d_Wx, bank->d_gx_off, bank->d_gx_L, bank->d_L,
+                           bank->d_cf, (int)bank->M, d_out);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}

@@ -476,6 +476,107 @@ TSR_API int tsr_score_bank_all_u8(tsr_ctx *ctx, const tsr_bank *bank, const uint
     return s;
 }
 
+// ---- phone-window classification -----------------------------------
+// get_train_data.py:718-773 over a resident corpus: windows are [start, end) frame ranges of the
+// stream, each inside one utterance.
+TSR_API int tsr_corpus_classify_windows(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, const int64_t *starts,
+                                        const int64_t *ends, int64_t W, int flags, float *score, int64_t *loc,
+                                        int32_t *template_id)
+{
+    TSR_REQUIRE(ctx && bank && cp && (W == 0 || (starts && ends && score && loc && template_id)),
+                "tsr_corpus_classify_windows: null pointer");
+    TSR_REQUIRE(W >= 0, "tsr_corpus_classify_windows: negative window count");
+    if (W == 0) return TSR_OK;
+    for (int64_t w = 0; w < W; ++w) {
+        TSR_REQUIRE(starts[w] >= 0 && starts[w] < ends[w] && ends[w] <= cp->P,
+                    "tsr_corpus_classify_windows: window %lld = [%lld, %lld) is empty or outside the %lld frames (np.argmax of an empty slice raises in the reference)",
+                    (long long)w, (long long)starts[w], (long long)ends[w], (long long)cp->P);
+        const auto it = std::upper_bound(cp->offsets.begin(), cp->offsets.end(), starts[w]);  // first offset > start
+        TSR_REQUIRE(it != cp->offsets.end() && ends[w] <= *it,
+                    "tsr_corpus_classify_windows: window %lld = [%lld, %lld) crosses an utterance boundary",
+                    (long long)w, (long long)starts[w], (long long)ends[w]);
+    }
+    TSR_HIP(hipSetDevice(ctx->device));
+    void *d_all = nullptr, *d_win = nullptr, *d_res = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_OUT, (size_t)bank->M * cp->P * sizeof(float), &d_all));
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX, (size_t)W * 16, &d_win));
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX2, (size_t)W * 16, &d_res));
+    int64_t *d_starts = (int64_t *)d_win, *d_ends = d_starts + W;
+    int64_t *d_loc = (int64_t *)d_res;
+    float *d_score = (float *)(d_loc + W);
+    int32_t *d_tid = (int32_t *)(d_score + W);
+    TSR_HIP(hipMemcpyAsync(d_starts, starts, (size_t)W * 8, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(d_ends, ends, (size_t)W * 8, hipMemcpyHostToDevice, ctx->stream));
+    TSR_TRY(corpus_score_impl(ctx, bank, cp, flags, (float *)d_all));
+    TSR_TRY(tsr_launch_window_argmax(ctx, (const float *)d_all, cp->P, (int)bank->M, d_starts, d_ends, W, d_score, d_loc, d_tid));
+    TSR_HIP(hipMemcpyAsync(score, d_score, (size_t)W * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(loc, d_loc, (size_t)W * 8, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(template_id, d_tid, (size_t)W * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    return TSR_OK;
+}
+
+// get_train_data.py:838-925: W background-padded f32 windows, rows concatenated in `E_cat`
+// (window w = rows [row_offsets[w], row_offsets[w+1])), arg-max over its first n_valid[w] positions.
+TSR_API int tsr_classify_float_windows(tsr_ctx *ctx, const tsr_bank *bank, const float *E_cat,
+                                       const int64_t *row_offsets, const int32_t *n_valid, int64_t W,
+                                       float *score, int32_t *loc, int32_t *template_id)
+{
+    TSR_REQUIRE(ctx && bank && (W == 0 || (E_cat && row_offsets && n_valid && score && loc && template_id)),
+                "tsr_classify_float_windows: null pointer");
+    TSR_REQUIRE(W >= 0, "tsr_classify_float_windows: negative window count");
+    if (W == 0) return TSR_OK;
+    TSR_REQUIRE(row_offsets[0] == 0, "tsr_classify_float_windows: row_offsets[0] must be 0");
+    std::vector<int64_t> starts((size_t)W), ends((size_t)W);
+    int64_t NW = 0;
+    for (int64_t w = 0; w < W; ++w) {
+        const int64_t T = row_offsets[w + 1] - row_offsets[w];
+        TSR_REQUIRE(T >= 1 && n_valid[w] >= 1 && n_valid[w] <= T,
+                    "tsr_classify_float_windows: window %lld has %lld rows and %d positions to search (np.argmax of an empty slice raises in the reference)",
+                    (long long)w, (long long)T, n_valid[w]);
+        for (int32_t m = 0; m < bank->M; ++m)
+            TSR_REQUIRE(T >= bank->L[m], "tsr_classify_float_windows: window %lld has %lld rows, template %d needs %d (the reference reads out of bounds here)",
+                        (long long)w, (long long)T, m, bank->L[m]);
+        starts[(size_t)w] = NW;
+        NW += n_valid[w];
+        ends[(size_t)w] = NW;
+    }
+    const int64_t R = row_offsets[W];
+    TSR_REQUIRE(R < ((int64_t)1 << 31) && NW < ((int64_t)1 << 31), "tsr_classify_float_windows: too many rows");
+    std::vector<int32_t> item_row((size_t)NW), item_left((size_t)NW);
+    for (int64_t w = 0; w < W; ++w)
+        for (int32_t t = 0; t < n_valid[w]; ++t) {
+            item_row[(size_t)(starts[(size_t)w] + t)] = (int32_t)(row_offsets[w] + t);
+            item_left[(size_t)(starts[(size_t)w] + t)] = (int32_t)(row_offsets[w + 1] - row_offsets[w] - t);
+        }
+    TSR_HIP(hipSetDevice(ctx->device));
+    void *dX = nullptr, *d_all = nullptr, *d_win = nullptr, *d_res = nullptr, *d_items = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_IN, (size_t)R * bank->D * 4, &dX));
+    TSR_TRY(tsr_scratch(ctx, SLOT_OUT, (size_t)bank->M * NW * 4, &d_all));
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX, (size_t)W * 16, &d_win));
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX2, (size_t)W * 16, &d_res));
+    TSR_TRY(tsr_scratch(ctx, SLOT_W, (size_t)NW * 8, &d_items));
+    int64_t *d_starts = (int64_t *)d_win, *d_ends = d_starts + W;
+    int64_t *d_loc = (int64_t *)d_res;
+    float *d_score = (float *)(d_loc + W);
+    int32_t *d_tid = (int32_t *)(d_score + W);
+    int32_t *d_row = (int32_t *)d_items, *d_left = d_row + NW;
+    TSR_HIP(hipMemcpyAsync(dX, E_cat, (size_t)R * bank->D * 4, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(d_starts, starts.data(), (size_t)W * 8, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(d_ends, ends.data(), (size_t)W * 8, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(d_row, item_row.data(), (size_t)NW * 4, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(d_left, item_left.data(), (size_t)NW * 4, hipMemcpyHostToDevice, ctx->stream));
+    TSR_TRY(tsr_launch_float_windows(ctx, bank, (const float *)dX, d_row, d_left, NW, (float *)d_all));
+    TSR_TRY(tsr_launch_window_argmax(ctx, (const float *)d_all, NW, (int)bank->M, d_starts, d_ends, W, d_score, d_loc, d_tid));
+    std::vector<int64_t> loc64((size_t)W);
+    TSR_HIP(hipMemcpyAsync(score, d_score, (size_t)W * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(loc64.data(), d_loc, (size_t)W * 8, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(template_id, d_tid, (size_t)W * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    for (int64_t w = 0; w < W; ++w) loc[w] = (int32_t)(loc64[(size_t)w] - starts[(size_t)w]);  // position inside the window
+    return TSR_OK;
+}
+
 // ---- single-utterance drop-ins ----------------------------------------------------
 TSR_API int tsr_detect_u8(tsr_ctx *ctx, const uint8_t *F, int64_t T, int64_t D, const float *LF,
                           int64_t L, float *out)

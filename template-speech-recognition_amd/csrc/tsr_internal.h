@@ -141,6 +141,11 @@ int tsr_launch_detect_f32(tsr_ctx *ctx, const float *d_F, int64_t T, int64_t D, 
 int tsr_launch_max_detect_examples(tsr_ctx *ctx, const uint8_t *d_F, int64_t N, int64_t T,
                                    int64_t D, const double *d_LF, int64_t L,
                                    const int64_t *d_lengths, double *d_tmp, double *d_out);
+// classify.hip
+int tsr_launch_window_argmax(tsr_ctx *ctx, const float *d_all, int64_t stride, int M, const int64_t *d_starts,
+                             const int64_t *d_ends, int64_t W, float *d_score, int64_t *d_loc, int32_t *d_tid);
+int tsr_launch_float_windows(tsr_ctx *ctx, const tsr_bank *bank, const float *d_X, const int32_t *d_item_row,
+                             const int32_t *d_item_left, int64_t NW, float *d_out);
 // parts_mfma.hip
 int tsr_parts_mfma_prepare(tsr_ctx *ctx, tsr_parts *p, const double *lp, const double *lip);
 void tsr_parts_mfma_free(tsr_parts *p);

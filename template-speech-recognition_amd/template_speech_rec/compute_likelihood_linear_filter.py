@@ -51,6 +51,11 @@ def _detect_f32(F, LF, ndim):
     return out
 
 
+def _check_float_features(F):
+    """The buffer acquisition detect_float / detect_float2d would perform on a feature window."""
+    return buffer(F, np.float32, 3 if getattr(F, "ndim", 0) != 2 else 2, "F", "DTYPE_t")
+
+
 def detect_float(F, LF):
     """:178-219.  float32 features [T, F, K] (e.g. background-padded windows)."""
     return _detect_f32(F, LF, 3)

@@ -4,6 +4,8 @@ the native kernels, re-hosted on the GPU path:
     reorg_part_for_fast_filtering / reorg_parts_for_fast_filtering   :41-57
     collapse_to_grid                                                  :72-81
     get_waliji_feature_map (from the edge map on)                     :182-191
+    get_classify_windows / _compute_classification_E                  :710-773
+    get_isolated_classify_windows / _compute_isolated_classification_E :781-925
     _compute_detection_E (scoring + template ids)                     :927-1012
     get_detection_scores_mixture_named_params (the corpus loop)       :1238-1339
     get_part_features (edge-only branch)                              :2576-2631
@@ -116,3 +118,86 @@ def get_detection_scores(utterances, linear_filters_cs, P_config=None, flags=api
         detection_array[n, :lengths[n]] = scores[offsets[n]:offsets[n + 1]]
         detection_template_ids[n, :lengths[n]] = ids[offsets[n]:offsets[n + 1]]
     return detection_array, detection_template_ids, lengths
+
+
+# ---- classification over phone windows (:710-925) ---------------------------------------------
+def get_classify_windows(phns, flts):
+    """:710-716 -- per phone the frame range in which its detection is looked for: a third of the
+    previous phone before its start to a third of its own length after it."""
+    flts = np.asarray(flts)
+    window_starts = np.maximum(0, flts[:-1] + (flts[:-1] - flts[1:]) / 3.).astype(np.int16)
+    window_ends = np.minimum(flts[-1], flts[:-1] + (flts[1:] - flts[:-1]) / 3.).astype(np.int16)
+    return window_starts, window_ends
+
+
+def _store_classification(utt_id, score, loc, tid, linear_filters_cs, classify_array, classify_template_ids,
+                          classify_template_lengths, classify_locs):
+    n = len(score)
+    classify_array[utt_id, :n] = score
+    classify_locs[utt_id, :n] = loc
+    classify_template_ids[utt_id, :n] = tid
+    classify_template_lengths[utt_id, :n] = [len(linear_filters_cs[t][0]) for t in tid]
+
+
+def _compute_classification_E(E, phns, E_flts, utt_id, classify_array, classify_template_ids,
+                              classify_template_lengths, classify_locs, linear_filters_cs,
+                              phn_mapping=None, verbose=False, flags=api.TSR_EXACT, bank=None):
+    """:718-773 -- for every phone of the utterance: the best detection score inside its window, where
+    (frame) and by which template (first maximum per template, earlier template on ties).  One scoring
+    pass + one windowed arg-max launch instead of a Python loop per (template, phone)."""
+    window_starts, window_ends = get_classify_windows(phns, E_flts)
+    E = np.asarray(E).astype(np.uint8)
+    bank = bank or api.Bank(linear_filters_cs)
+    corpus = api.Corpus(E.reshape(E.shape[0], -1), [0, E.shape[0]], ctx=bank.ctx)
+    score, loc, tid = corpus.classify_windows(bank, window_starts, window_ends, flags=flags)
+    _store_classification(utt_id, score, loc, tid, linear_filters_cs, classify_array, classify_template_ids,
+                          classify_template_lengths, classify_locs)
+
+
+def get_isolated_classify_windows(E, phns, flts, bgd, linear_filters_cs, max_length=None):
+    """:781-835 -- one background-padded f32 feature window per phone.  Like the reference this shifts
+    `flts` IN PLACE by the front padding; returns (E_windows, window_starts, window_ends, flts[0])."""
+    if max_length is None:
+        max_filter_length = max(len(lfc[0]) for lfc in linear_filters_cs)
+    else:
+        max_filter_length = max_length
+    max_phn_length_third = int(np.ceil(np.max(flts[1:] - flts[:-1]) / 3.))
+    ones = (1,) * len(bgd.shape)
+    E = np.vstack((
+        np.tile(bgd, (max_filter_length + max_phn_length_third,) + ones).astype(np.float32),
+        E.astype(np.float32),
+        np.tile(bgd, (max(0, int(flts[-2]) + max_phn_length_third + max_filter_length - int(flts[-1])),)
+                + ones).astype(np.float32)))
+    flts += max_filter_length + max_phn_length_third
+    window_starts = (flts[:-1] + (flts[:-1] - flts[1:]) / 3.).astype(np.int16)
+    window_ends = (flts[:-1] + (flts[1:] - flts[:-1]) / 3.).astype(np.int16)
+    phn_segment_ends = (flts[1:] + (flts[1:] - flts[:-1]) / 3.).astype(np.int16)
+    E_windows = tuple(
+        np.vstack((E[int(ws):int(pse)].astype(np.float32),
+                   np.tile(bgd, (max(0, int(we) + max_filter_length - int(pse)),) + ones)))
+        for ws, we, pse in zip(window_starts, window_ends, phn_segment_ends))
+    return E_windows, window_starts, window_ends, flts[0]
+
+
+def _compute_isolated_classification_E(E, phns, E_flts, utt_id, classify_array, classify_template_ids,
+                                       classify_template_lengths, classify_locs, linear_filters_cs, bgd,
+                                       phn_mapping=None, verbose=False, svm_classifiers=None,
+                                       svm_constants=None, svm_classify_array=None, bank=None):
+    """:838-925 -- every phone is scored in isolation on its own background-padded window
+    (detect_float / detect_float2d + c), all windows and templates of the utterance in one launch.
+    The optional linear-SVM re-scoring of the winning window (:913-921) is a NumPy expression in the
+    reference and stays one here."""
+    E_windows, window_starts, window_ends, flt_front_pad = get_isolated_classify_windows(
+        E, phns, E_flts, bgd, linear_filters_cs)
+    for w in E_windows:   # the Cython buffer check of detect_float (a float64 bgd ends here in the reference too)
+        compute_likelihood_linear_filter._check_float_features(w)
+    bank = bank or api.Bank(linear_filters_cs)
+    n_valid = window_ends.astype(np.int64) - window_starts.astype(np.int64)
+    score, pos, tid = bank.classify_float_windows(E_windows, n_valid)
+    loc = window_starts.astype(np.int64) + pos - int(flt_front_pad)
+    _store_classification(utt_id, score, loc, tid, linear_filters_cs, classify_array, classify_template_ids,
+                          classify_template_lengths, classify_locs)
+    if svm_classifiers is not None and svm_classify_array is not None:
+        for phn_id, (E_window, p) in enumerate(zip(E_windows, pos)):
+            t, n = int(tid[phn_id]), len(linear_filters_cs[int(tid[phn_id])][0])
+            svm_classify_array[utt_id, phn_id] = (E_window[p:p + n] * svm_classifiers[t]).sum() + svm_constants[t]

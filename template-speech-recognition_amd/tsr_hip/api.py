@@ -126,6 +126,25 @@ class Bank:
         """RCCL broadcast of the bank from `root` to every rank (ctx.dist_init first)."""
         check(lib().tsr_bank_broadcast(self.ctx._h, self._h, int(root)))
 
+    def classify_float_windows(self, E_windows, n_valid):
+        """detect_float + c on each background-padded f32 window, arg-max over its first
+        n_valid[w] positions, best template (get_train_data.py:838-925) ->
+        (score f32 [W], position inside the window i32 [W], template i32 [W])."""
+        wins = [np.ascontiguousarray(w, dtype=np.float32).reshape(len(w), -1) for w in E_windows]
+        for w in wins:
+            if w.shape[1] != self.D:
+                raise ValueError("window rows have %d features, the bank %d" % (w.shape[1], self.D))
+        W = len(wins)
+        offs = np.concatenate(([0], np.cumsum([w.shape[0] for w in wins]))).astype(np.int64)
+        cat = np.concatenate(wins) if W else np.zeros((0, self.D), np.float32)
+        nv = np.ascontiguousarray(n_valid, dtype=np.int32)
+        if nv.shape != (W,):
+            raise ValueError("n_valid must have one entry per window")
+        score, loc, tid = np.empty(W, np.float32), np.empty(W, np.int32), np.empty(W, np.int32)
+        check(lib().tsr_classify_float_windows(self.ctx._h, self._h, ptr(cat), ptr(offs), ptr(nv), W,
+                                               ptr(score), ptr(loc), ptr(tid)))
+        return score, loc, tid
+
     # ---- scoring ---------------------------------------------------------------------
     def _offsets(self, feats, frame_offsets):
         feats = np.ascontiguousarray(feats, dtype=np.uint8)
@@ -217,6 +236,19 @@ class Corpus:
     def score(self, bank, flags=TSR_EXACT):
         """Enqueue one scoring pass on the ctx stream (asynchronous)."""
         check(lib().tsr_corpus_score(self.ctx._h, bank._h, self._h, int(flags)))
+
+    def classify_windows(self, bank, starts, ends, flags=TSR_EXACT):
+        """Best (score, stream frame, template) per phone window [start, end) of the frame stream
+        (get_train_data.py:718-773) -> (f32 [W], i64 [W], i32 [W])."""
+        starts = np.ascontiguousarray(starts, dtype=np.int64)
+        ends = np.ascontiguousarray(ends, dtype=np.int64)
+        if starts.shape != ends.shape or starts.ndim != 1:
+            raise ValueError("starts/ends must be equal-length 1-d arrays")
+        W = starts.shape[0]
+        score, loc, tid = np.empty(W, np.float32), np.empty(W, np.int64), np.empty(W, np.int32)
+        check(lib().tsr_corpus_classify_windows(self.ctx._h, bank._h, self._h, ptr(starts), ptr(ends), W,
+                                                int(flags), ptr(score), ptr(loc), ptr(tid)))
+        return score, loc, tid
 
     def download(self):
         scores = np.empty(self.P, np.float32)

@@ -447,3 +447,87 @@ def test_config3_fullsize_coders_agree(mods, oracle):
     so, ao = oracle.score_bank(got[n0], bank_cs)
     sl = slice(pc_mfma.offsets[n0], pc_mfma.offsets[n0 + 1])
     assert np.array_equal(se[sl], so) and np.array_equal(ae[sl], ao)
+
+
+# ---- phone-window classification ------------------------------------------------
+def _golden_classify(name):
+    g = golden(name)
+    bank = [(g["W%d" % m], float(g["c%d" % m])) for m in range(int(g["M"]))]
+    utts = []
+    for u in range(int(g["N"])):
+        shape = tuple(int(x) for x in g["Eshape%d" % u])
+        E = np.unpackbits(g["E%d" % u])[:int(np.prod(shape))].reshape(shape)
+        utts.append((E, g["flts%d" % u]))
+    return g, bank, utts
+
+
+@pytest.mark.parametrize("isolated", [False, True])
+def test_classification_golden(mods, isolated):
+    """g12 / g13: the reference's compiled detect / detect_float under the restated glue."""
+    import template_speech_rec.get_train_data as gtrd
+    g, bank, utts = _golden_classify("g13_isolated_classification_E" if isolated else "g12_classification_E")
+    want = {k: g[k] for k in ("classify_array", "classify_template_ids", "classify_template_lengths", "classify_locs")}
+    arr = np.zeros_like(want["classify_array"])
+    ids = np.zeros_like(want["classify_template_ids"])
+    lens = np.zeros_like(want["classify_template_lengths"])
+    locs = np.zeros_like(want["classify_locs"])
+    for u, (E, flts) in enumerate(utts):
+        if isolated:
+            gtrd._compute_isolated_classification_E(E, None, flts.copy(), u, arr, ids, lens, locs, bank, g["q"])
+        else:
+            gtrd._compute_classification_E(E, None, flts.copy(), u, arr, ids, lens, locs, bank)
+    assert np.array_equal(arr, want["classify_array"])
+    assert np.array_equal(locs, want["classify_locs"])
+    assert np.array_equal(ids, want["classify_template_ids"])
+    assert np.array_equal(lens, want["classify_template_lengths"])
+    assert (ids != 3).all()          # template 3 duplicates template 1: the earlier one keeps the tie
+
+
+def test_classification_random_vs_oracle(mods, oracle):
+    tsr_hip = mods[3]
+    import template_speech_rec.get_train_data as gtrd
+    from tsr_hip import synth
+    rng = np.random.default_rng(99)
+    q = synth.background(rng, (11, 8)).astype(np.float32)
+    bank = synth.bank(rng, q, [5, 17, 9, 12, 17, 3, 8, 11, 6, 10])     # two groups of templates (MG = 8)
+    for T in (57, 140, 33):
+        E = synth.features(rng, T, q)
+        cuts = np.sort(rng.choice(np.arange(4, T - 3), size=max(2, T // 15), replace=False))
+        flts = np.concatenate(([0], cuts, [T])).astype(np.int64)
+        nph = len(flts) - 1
+        for isolated in (False, True):
+            got = [np.zeros((1, nph), dt) for dt in (np.float32, np.uint16, np.uint16, np.int16)]
+            ref = [np.zeros((1, nph), dt) for dt in (np.float32, np.uint16, np.uint16, np.int16)]
+            if isolated:
+                gtrd._compute_isolated_classification_E(E, None, flts.copy(), 0, got[0], got[1], got[2], got[3], bank, q)
+                oracle.compute_isolated_classification_E(E, None, flts.copy(), 0, ref[0], ref[1], ref[2], ref[3], bank, q)
+            else:
+                gtrd._compute_classification_E(E, None, flts.copy(), 0, got[0], got[1], got[2], got[3], bank)
+                oracle.compute_classification_E(E, None, flts.copy(), 0, ref[0], ref[1], ref[2], ref[3], bank)
+            for a, b in zip(got, ref):
+                assert np.array_equal(a, b), (T, isolated)
+    # the MFMA scores give the same winners unless two candidates are within the quantisation noise
+    E = synth.features(rng, 200, q)
+    flts = np.arange(0, 201, 20, dtype=np.int64)
+    corpus = tsr_hip.Corpus(E.reshape(200, -1), [0, 200])
+    b = tsr_hip.Bank(bank)
+    ws, we = gtrd.get_classify_windows(None, flts)
+    se, le, te = corpus.classify_windows(b, ws, we, tsr_hip.TSR_EXACT)
+    sf, lf, tf = corpus.classify_windows(b, ws, we, tsr_hip.TSR_FAST)
+    assert rel_err(sf, se) <= TOL
+    with pytest.raises(ValueError):
+        corpus.classify_windows(b, [5], [5], tsr_hip.TSR_EXACT)           # empty window
+    with pytest.raises(ValueError):
+        tsr_hip.Corpus(np.concatenate([E, E]).reshape(400, -1), [0, 200, 400]).classify_windows(b, [190], [210])
+
+
+def test_isolated_windows_reject_float64_background(mods):
+    import template_speech_rec.get_train_data as gtrd
+    from tsr_hip import synth
+    rng = np.random.default_rng(4)
+    q = synth.background(rng, (6, 8))                                      # float64, as np.clip returns it
+    bank = synth.bank(rng, q, [5, 7])
+    E = synth.features(rng, 60, q)
+    z = [np.zeros((1, 3), dt) for dt in (np.float32, np.uint16, np.uint16, np.int16)]
+    with pytest.raises(ValueError, match="Buffer dtype mismatch, expected 'DTYPE_t' but got 'double'"):
+        gtrd._compute_isolated_classification_E(E, None, np.array([0, 20, 41, 60]), 0, z[0], z[1], z[2], z[3], bank, q)

@@ -185,3 +185,24 @@ def test_oracle_handles_T_less_than_L(oracle):
     allm = oracle.score_bank_all(X, bank)
     assert np.all(allm[1] == np.float32(bank[1][1]))
     assert np.array_equal(s, allm.max(0))
+
+
+@pytest.mark.parametrize("isolated", [False, True])
+def test_classification_restatement_matches_golden(oracle, isolated):
+    """g12 / g13 were produced by the reference's compiled detect / detect_float under the restated
+    glue; the oracle's own C restatements must give the same arrays bit for bit."""
+    g = golden("g13_isolated_classification_E" if isolated else "g12_classification_E")
+    bank = [(g["W%d" % m], float(g["c%d" % m])) for m in range(int(g["M"]))]
+    want = [g[k] for k in ("classify_array", "classify_template_ids", "classify_template_lengths", "classify_locs")]
+    got = [np.zeros_like(w) for w in want]
+    for u in range(int(g["N"])):
+        shape = tuple(int(x) for x in g["Eshape%d" % u])
+        E = np.unpackbits(g["E%d" % u])[:int(np.prod(shape))].reshape(shape)
+        flts = g["flts%d" % u].copy()
+        if isolated:
+            oracle.compute_isolated_classification_E(E, None, flts, u, got[0], got[1], got[2], got[3], bank, g["q"])
+            assert flts[0] > 0          # shifted in place, like the reference
+        else:
+            oracle.compute_classification_E(E, None, flts, u, got[0], got[1], got[2], got[3], bank)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
