@@ -197,6 +197,17 @@ int tsr_classify_float_windows(tsr_ctx *ctx, const tsr_bank *bank, const float *
                                const int64_t *row_offsets, const int32_t *n_valid, int64_t W,
                                float *score, int32_t *loc, int32_t *template_id);
 
+/* The same on a resident BINARY corpus without materialising the windows (which are ~40 f32 rows per
+ * phone, 4 KB per row at D=360): window w starts at stream frame first[w] -- possibly before its
+ * utterance (front padding) -- has rows[w] rows, of which those whose frame lies in
+ * [real_lo[w], real_hi[w]) are the corpus frames (as 0.0f/1.0f) and all others the background vector
+ * bgd f32 [D] (the padding of :791-803 and the rows behind the phone's segment end, :826-832).
+ * Identical scores to tsr_classify_float_windows on the materialised windows. */
+int tsr_corpus_classify_isolated(tsr_ctx *ctx, const tsr_bank *bank, const tsr_corpus *corpus,
+                                 const float *bgd, const int64_t *first, const int64_t *real_lo,
+                                 const int64_t *real_hi, const int32_t *rows, const int32_t *n_valid,
+                                 int64_t W, float *score, int32_t *loc, int32_t *template_id);
+
 /* ---- multi-GPU: utterances shard across ranks, the bank is broadcast once ----- */
 /* One process per GPU.  Rank 0 calls tsr_dist_unique_id and hands the 128 bytes
  * to the other ranks over any host channel; every rank then calls

@@ -126,6 +126,60 @@ __global__ __launch_bounds__(kThreads) void float_windows_kernel(
     }
 }
 
+// The isolated-classification windows WITHOUT materialising them: window item i looks at the
+// frames f = first[i] + tau of the resident binary corpus; a frame inside [lo[i], hi[i]) is real
+// (bytes 0/1 -> 0.0f/1.0f), every other row of the window is the background vector `bgd`
+// (front/tail padding of the utterance and the rows behind the phone's segment end,
+// get_train_data.py:791-832).  Arithmetic and order as float_windows_kernel, so the scores are those
+// of detect_float on the materialised window, bit for bit.
+__global__ __launch_bounds__(kThreads) void isolated_windows_kernel(
+    const uint8_t *__restrict__ X, int Dp, int D, int WR32, const float *__restrict__ bgd,
+    const int64_t *__restrict__ item_first, const int64_t *__restrict__ item_lo, const int64_t *__restrict__ item_hi,
+    const int32_t *__restrict__ item_left, int64_t NW, const float *__restrict__ Wx,
+    const int64_t *__restrict__ gx_off, const int32_t *__restrict__ gx_L, const int32_t *__restrict__ Lm,
+    const float *__restrict__ cf, int M, float *__restrict__ out)
+{
+#pragma clang fp contract(off)  // the reference rounds the product to f32 before the add
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int g = blockIdx.y;
+    const bool on = i < NW;
+    const int64_t first = on ? item_first[i] : 0, lo = on ? item_lo[i] : 0, hi = on ? item_hi[i] : 0;
+    const int left = on ? item_left[i] : 0;
+    const float *__restrict__ wg = Wx + gx_off[g];
+    const int Lg = gx_L[g];
+    float acc[TSR_MG];
+#pragma unroll
+    for (int j = 0; j < TSR_MG; ++j) acc[j] = 0.0f;
+    for (int tau = 0; tau < Lg; ++tau) {
+        const int64_t f = first + tau;
+        const bool real = f >= lo && f < hi;
+        const uint8_t *__restrict__ x = X + (real ? f : 0) * (int64_t)Dp;
+        const float *__restrict__ wt = wg + (int64_t)tau * WR32 * TSR_MG;
+        for (int d0 = 0; d0 < D; d0 += 16) {  // resident rows are 16-byte multiples (zero padded)
+            const uint4 xv = *reinterpret_cast<const uint4 *>(x + d0);
+            const uint32_t xw[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (d0 + u < D) {  // uniform
+                    const float xb = (float)((xw[u >> 2] >> (8 * (u & 3))) & 0xffu);
+                    const float xs = real ? xb : bgd[d0 + u];
+#pragma unroll
+                    for (int j = 0; j < TSR_MG; ++j) {
+                        const float prod = wt[(d0 + u) * TSR_MG + j] * xs;
+                        acc[j] = acc[j] + prod;
+                    }
+                }
+            }
+        }
+    }
+    if (!on) return;
+#pragma unroll
+    for (int j = 0; j < TSR_MG; ++j) {
+        const int m = g * TSR_MG + j;
+        if (m < M) out[(int64_t)m * NW + i] = (Lm[m] <= left ? acc[j] : 0.0f) + cf[m];
+    }
+}
+
 }  // namespace
 
 int tsr_launch_window_argmax(tsr_ctx *ctx, const float *d_all, int64_t stride, int M, const int64_t *d_starts,
@@ -153,6 +207,19 @@ int tsr_launch_float_windows(tsr_ctx *ctx, const tsr_bank *bank, const float *d_
         hipLaunchKernelGGL(float_windows_kernel<false>, grid, dim3(kThreads), 0, ctx->stream, d_X, D, bank->Dq * 32,
                            d_item_row, d_item_left, NW, bank->d_Wx, bank->d_gx_off, bank->d_gx_L, bank->d_L,
                            bank->d_cf, (int)bank->M, d_out);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+
+int tsr_launch_isolated_windows(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *d_X, int Dp, const float *d_bgd,
+                                const int64_t *d_first, const int64_t *d_lo, const int64_t *d_hi,
+                                const int32_t *d_left, int64_t NW, float *d_out)
+{
+    if (NW <= 0) return TSR_OK;
+    dim3 grid((unsigned)((NW + kThreads - 1) / kThreads), (unsigned)bank->n_groups);
+    hipLaunchKernelGGL(isolated_windows_kernel, grid, dim3(kThreads), 0, ctx->stream, d_X, Dp, (int)bank->D,
+                       bank->Dq * 32, d_bgd, d_first, d_lo, d_hi, d_left, NW, bank->d_Wx, bank->d_gx_off, bank->d_gx_L,
+                       bank->d_L, bank->d_cf, (int)bank->M, d_out);
     TSR_HIP(hipGetLastError());
     return TSR_OK;
 }

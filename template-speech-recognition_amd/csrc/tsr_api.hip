@@ -577,6 +577,76 @@ TSR_API int tsr_classify_float_windows(tsr_ctx *ctx, const tsr_bank *bank, const
     return TSR_OK;
 }
 
+// get_train_data.py:781-925 over a resident binary corpus, the windows never materialised: window w
+// starts at stream frame first[w] (may lie before its utterance: front padding), its rows are real
+// corpus frames inside [real_lo[w], real_hi[w]) and the background vector everywhere else, it has
+// rows[w] rows in total and its first n_valid[w] positions are searched.
+TSR_API int tsr_corpus_classify_isolated(tsr_ctx *ctx, const tsr_bank *bank, const tsr_corpus *cp, const float *bgd,
+                                         const int64_t *first, const int64_t *real_lo, const int64_t *real_hi,
+                                         const int32_t *rows, const int32_t *n_valid, int64_t W, float *score,
+                                         int32_t *loc, int32_t *template_id)
+{
+    TSR_REQUIRE(ctx && bank && cp && bgd && (W == 0 || (first && real_lo && real_hi && rows && n_valid && score && loc && template_id)),
+                "tsr_corpus_classify_isolated: null pointer");
+    TSR_REQUIRE(bank->D == cp->D, "tsr_corpus_classify_isolated: bank D=%lld but corpus D=%lld", (long long)bank->D, (long long)cp->D);
+    TSR_REQUIRE(W >= 0, "tsr_corpus_classify_isolated: negative window count");
+    if (W == 0) return TSR_OK;
+    std::vector<int64_t> starts((size_t)W), ends((size_t)W);
+    int64_t NW = 0;
+    for (int64_t w = 0; w < W; ++w) {
+        TSR_REQUIRE(rows[w] >= 1 && n_valid[w] >= 1 && n_valid[w] <= rows[w],
+                    "tsr_corpus_classify_isolated: window %lld has %d rows and %d positions to search (np.argmax of an empty slice raises in the reference)",
+                    (long long)w, rows[w], n_valid[w]);
+        TSR_REQUIRE(real_lo[w] >= 0 && real_hi[w] <= cp->P && real_lo[w] <= real_hi[w],
+                    "tsr_corpus_classify_isolated: window %lld: real frames [%lld, %lld) outside the corpus", (long long)w, (long long)real_lo[w], (long long)real_hi[w]);
+        for (int32_t m = 0; m < bank->M; ++m)
+            TSR_REQUIRE(rows[w] >= bank->L[m], "tsr_corpus_classify_isolated: window %lld has %d rows, template %d needs %d (the reference reads out of bounds here)",
+                        (long long)w, rows[w], m, bank->L[m]);
+        starts[(size_t)w] = NW;
+        NW += n_valid[w];
+        ends[(size_t)w] = NW;
+    }
+    TSR_REQUIRE(NW < ((int64_t)1 << 31), "tsr_corpus_classify_isolated: too many positions");
+    std::vector<int64_t> it((size_t)NW * 3);
+    std::vector<int32_t> left((size_t)NW);
+    for (int64_t w = 0; w < W; ++w)
+        for (int32_t t = 0; t < n_valid[w]; ++t) {
+            const size_t i = (size_t)(starts[(size_t)w] + t);
+            it[i] = first[w] + t;
+            it[(size_t)NW + i] = real_lo[w];
+            it[(size_t)2 * NW + i] = real_hi[w];
+            left[i] = rows[w] - t;
+        }
+    TSR_HIP(hipSetDevice(ctx->device));
+    void *d_all = nullptr, *d_win = nullptr, *d_res = nullptr, *d_items = nullptr, *d_bgd = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_OUT, (size_t)bank->M * NW * 4, &d_all));
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX, (size_t)W * 16, &d_win));
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX2, (size_t)W * 16, &d_res));
+    TSR_TRY(tsr_scratch(ctx, SLOT_W, (size_t)NW * 28, &d_items));
+    TSR_TRY(tsr_scratch(ctx, SLOT_IN, (size_t)bank->D * 4, &d_bgd));
+    int64_t *d_starts = (int64_t *)d_win, *d_ends = d_starts + W;
+    int64_t *d_loc = (int64_t *)d_res;
+    float *d_score = (float *)(d_loc + W);
+    int32_t *d_tid = (int32_t *)(d_score + W);
+    int64_t *d_first = (int64_t *)d_items;
+    int32_t *d_left = (int32_t *)(d_first + 3 * NW);
+    TSR_HIP(hipMemcpyAsync(d_bgd, bgd, (size_t)bank->D * 4, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(d_starts, starts.data(), (size_t)W * 8, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(d_ends, ends.data(), (size_t)W * 8, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(d_first, it.data(), (size_t)NW * 24, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(d_left, left.data(), (size_t)NW * 4, hipMemcpyHostToDevice, ctx->stream));
+    TSR_TRY(tsr_launch_isolated_windows(ctx, bank, cp->d_feats, cp->Dp, (const float *)d_bgd, d_first, d_first + NW,
+                                        d_first + 2 * NW, d_left, NW, (float *)d_all));
+    TSR_TRY(tsr_launch_window_argmax(ctx, (const float *)d_all, NW, (int)bank->M, d_starts, d_ends, W, d_score, d_loc, d_tid));
+    std::vector<int64_t> loc64((size_t)W);
+    TSR_HIP(hipMemcpyAsync(score, d_score, (size_t)W * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(loc64.data(), d_loc, (size_t)W * 8, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(template_id, d_tid, (size_t)W * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    for (int64_t w = 0; w < W; ++w) loc[w] = (int32_t)(loc64[(size_t)w] - starts[(size_t)w]);
+    return TSR_OK;
+}
+
 // ---- single-utterance drop-ins ----------------------------------------------------
 TSR_API int tsr_detect_u8(tsr_ctx *ctx, const uint8_t *F, int64_t T, int64_t D, const float *LF,
                           int64_t L, float *out)

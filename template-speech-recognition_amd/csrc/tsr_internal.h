@@ -146,6 +146,9 @@ int tsr_launch_window_argmax(tsr_ctx *ctx, const float *d_all, int64_t stride, i
                              const int64_t *d_ends, int64_t W, float *d_score, int64_t *d_loc, int32_t *d_tid);
 int tsr_launch_float_windows(tsr_ctx *ctx, const tsr_bank *bank, const float *d_X, const int32_t *d_item_row,
                              const int32_t *d_item_left, int64_t NW, float *d_out);
+int tsr_launch_isolated_windows(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *d_X, int Dp, const float *d_bgd,
+                                const int64_t *d_first, const int64_t *d_lo, const int64_t *d_hi,
+                                const int32_t *d_left, int64_t NW, float *d_out);
 // parts_mfma.hip
 int tsr_parts_mfma_prepare(tsr_ctx *ctx, tsr_parts *p, const double *lp, const double *lip);
 void tsr_parts_mfma_free(tsr_parts *p);

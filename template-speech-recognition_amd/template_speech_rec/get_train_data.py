@@ -179,25 +179,103 @@ def get_isolated_classify_windows(E, phns, flts, bgd, linear_filters_cs, max_len
     return E_windows, window_starts, window_ends, flts[0]
 
 
+def _isolated_virtual_windows(T, flts, max_filter_length, frame0=0):
+    """The windows of get_isolated_classify_windows described instead of built: for every phone the
+    stream frame of its first row (frame0 = first frame of the utterance; rows before it are front
+    padding), the range of real frames, the row count and the number of searched positions -- what
+    tsr_corpus_classify_isolated consumes.  Also returns (window_starts, front pad) for the locations."""
+    flts = np.asarray(flts, dtype=np.int64)
+    max_phn_length_third = int(np.ceil(np.max(flts[1:] - flts[:-1]) / 3.))
+    pad = max_filter_length + max_phn_length_third
+    len_padded = pad + T + max(0, int(flts[-2]) + max_phn_length_third + max_filter_length - int(flts[-1]))
+    f = flts + pad
+    ws = (f[:-1] + (f[:-1] - f[1:]) / 3.).astype(np.int16).astype(np.int64)
+    we = (f[:-1] + (f[1:] - f[:-1]) / 3.).astype(np.int16).astype(np.int64)
+    pse = (f[1:] + (f[1:] - f[:-1]) / 3.).astype(np.int16).astype(np.int64)
+    avail_end = np.minimum(pse, len_padded)                     # E[ws:pse] clips at the padded length
+    rows = (avail_end - ws) + np.maximum(0, we + max_filter_length - pse)
+    first = frame0 + ws - pad
+    real_hi = frame0 + np.clip(avail_end - pad, 0, T)
+    real_lo = np.full_like(first, frame0)
+    return first, real_lo, real_hi, rows, we - ws, ws, int(f[0]), pad
+
+
 def _compute_isolated_classification_E(E, phns, E_flts, utt_id, classify_array, classify_template_ids,
                                        classify_template_lengths, classify_locs, linear_filters_cs, bgd,
                                        phn_mapping=None, verbose=False, svm_classifiers=None,
                                        svm_constants=None, svm_classify_array=None, bank=None):
     """:838-925 -- every phone is scored in isolation on its own background-padded window
-    (detect_float / detect_float2d + c), all windows and templates of the utterance in one launch.
+    (detect_float / detect_float2d + c).  The windows are not built: the kernel reads the binary map
+    and substitutes the background vector for every padding row, all phones and templates of the
+    utterance in one launch.  Like the reference this shifts `E_flts` IN PLACE by the front padding.
     The optional linear-SVM re-scoring of the winning window (:913-921) is a NumPy expression in the
     reference and stays one here."""
-    E_windows, window_starts, window_ends, flt_front_pad = get_isolated_classify_windows(
-        E, phns, E_flts, bgd, linear_filters_cs)
-    for w in E_windows:   # the Cython buffer check of detect_float (a float64 bgd ends here in the reference too)
-        compute_likelihood_linear_filter._check_float_features(w)
+    bgd = np.asarray(bgd)
+    E = np.asarray(E)
+    if bgd.dtype != np.float32:   # the f32 windows would be promoted and detect_float's buffer check raise
+        compute_likelihood_linear_filter._check_float_features(np.zeros((1,) + bgd.shape, bgd.dtype))
+    max_filter_length = max(len(lfc[0]) for lfc in linear_filters_cs)
+    first, lo, hi, rows, n_valid, ws, flt_front_pad, pad = _isolated_virtual_windows(E.shape[0], E_flts, max_filter_length)
+    if svm_classifiers is not None and svm_classify_array is not None:
+        E_windows = get_isolated_classify_windows(E, phns, np.array(E_flts), bgd, linear_filters_cs)[0]
+    E_flts += pad
     bank = bank or api.Bank(linear_filters_cs)
-    n_valid = window_ends.astype(np.int64) - window_starts.astype(np.int64)
-    score, pos, tid = bank.classify_float_windows(E_windows, n_valid)
-    loc = window_starts.astype(np.int64) + pos - int(flt_front_pad)
-    _store_classification(utt_id, score, loc, tid, linear_filters_cs, classify_array, classify_template_ids,
-                          classify_template_lengths, classify_locs)
+    E8 = E.astype(np.uint8)
+    corpus = api.Corpus(E8.reshape(E8.shape[0], -1), [0, E8.shape[0]], ctx=bank.ctx)
+    score, pos, tid = corpus.classify_isolated(bank, bgd, first, lo, hi, rows, n_valid)
+    _store_classification(utt_id, score, ws + pos - flt_front_pad, tid, linear_filters_cs, classify_array,
+                          classify_template_ids, classify_template_lengths, classify_locs)
     if svm_classifiers is not None and svm_classify_array is not None:
         for phn_id, (E_window, p) in enumerate(zip(E_windows, pos)):
             t, n = int(tid[phn_id]), len(linear_filters_cs[int(tid[phn_id])][0])
             svm_classify_array[utt_id, phn_id] = (E_window[p:p + n] * svm_classifiers[t]).sum() + svm_constants[t]
+
+
+def get_classify_scores_E(utterances, flts_list, linear_filters_cs, bgd=None, isolated=False,
+                          flags=api.TSR_EXACT, ctx=None):
+    """The corpus loop of get_classify_scores (:1341-1441) from the feature maps on, batched: every
+    phone window of every utterance in one launch.  `utterances[n]` is a binary map [T_n, ...],
+    `flts_list[n]` its phone boundaries (frames, len = phones + 1; not modified).  isolated=False is
+    _compute_classification_E, isolated=True _compute_isolated_classification_E (needs the f32 `bgd`).
+    Returns (classify_array f32, classify_locs i16, classify_template_lengths u16,
+    classify_template_ids u16), each [N, max phones], as the reference allocates them."""
+    N = len(utterances)
+    nph = max((len(f) - 1 for f in flts_list), default=0)
+    classify_array = np.zeros((N, nph), np.float32)
+    classify_template_ids = np.zeros((N, nph), np.uint16)
+    classify_locs = np.zeros((N, nph), np.int16)
+    classify_template_lengths = np.zeros((N, nph), np.uint16)
+    bank = api.Bank(linear_filters_cs, ctx=ctx)
+    if not isolated:
+        maps = [np.asarray(E).astype(np.uint8) for E in utterances]
+        offs = np.concatenate(([0], np.cumsum([m.shape[0] for m in maps]))).astype(np.int64)
+        corpus = api.Corpus(np.concatenate([m.reshape(m.shape[0], -1) for m in maps]), offs, ctx=bank.ctx)
+        wins = [get_classify_windows(None, f) for f in flts_list]
+        starts = np.concatenate([ws.astype(np.int64) + offs[n] for n, (ws, _) in enumerate(wins)])
+        ends = np.concatenate([we.astype(np.int64) + offs[n] for n, (_, we) in enumerate(wins)])
+        score, loc, tid = corpus.classify_windows(bank, starts, ends, flags=flags)
+        k = 0
+        for n, (ws, _) in enumerate(wins):
+            m = len(ws)
+            _store_classification(n, score[k:k + m], loc[k:k + m] - offs[n], tid[k:k + m], linear_filters_cs,
+                                  classify_array, classify_template_ids, classify_template_lengths, classify_locs)
+            k += m
+        return classify_array, classify_locs, classify_template_lengths, classify_template_ids
+    bgd = np.asarray(bgd)
+    if bgd.dtype != np.float32:
+        compute_likelihood_linear_filter._check_float_features(np.zeros((1,) + bgd.shape, bgd.dtype))
+    maps = [np.asarray(E).astype(np.uint8) for E in utterances]
+    offs = np.concatenate(([0], np.cumsum([m.shape[0] for m in maps]))).astype(np.int64)
+    corpus = api.Corpus(np.concatenate([m.reshape(m.shape[0], -1) for m in maps]), offs, ctx=bank.ctx)
+    Lmax = max(len(lfc[0]) for lfc in linear_filters_cs)
+    per = [_isolated_virtual_windows(m.shape[0], f, Lmax, frame0=int(offs[n]))
+           for n, (m, f) in enumerate(zip(maps, flts_list))]
+    cat = [np.concatenate([p[i] for p in per]) for i in range(5)]
+    score, pos, tid = corpus.classify_isolated(bank, bgd, *cat)
+    k = 0
+    for n, p in enumerate(per):
+        m = len(p[5])
+        _store_classification(n, score[k:k + m], p[5] + pos[k:k + m] - p[6], tid[k:k + m], linear_filters_cs,
+                              classify_array, classify_template_ids, classify_template_lengths, classify_locs)
+        k += m
+    return classify_array, classify_locs, classify_template_lengths, classify_template_ids

@@ -250,6 +250,22 @@ class Corpus:
                                                 int(flags), ptr(score), ptr(loc), ptr(tid)))
         return score, loc, tid
 
+    def classify_isolated(self, bank, bgd, first, real_lo, real_hi, rows, n_valid):
+        """Isolated-phone classification (get_train_data.py:781-925) with virtual windows: see
+        tsr_corpus_classify_isolated -> (score f32 [W], position inside the window i32 [W], template i32 [W])."""
+        bgd = np.ascontiguousarray(bgd, dtype=np.float32).reshape(-1)
+        if bgd.size != self.D:
+            raise ValueError("bgd has %d values, the corpus D=%d" % (bgd.size, self.D))
+        a = [np.ascontiguousarray(x, dtype=np.int64) for x in (first, real_lo, real_hi)]
+        b = [np.ascontiguousarray(x, dtype=np.int32) for x in (rows, n_valid)]
+        W = a[0].shape[0]
+        if any(x.shape != (W,) for x in a + b):
+            raise ValueError("per-window arrays must be 1-d and equally long")
+        score, loc, tid = np.empty(W, np.float32), np.empty(W, np.int32), np.empty(W, np.int32)
+        check(lib().tsr_corpus_classify_isolated(self.ctx._h, bank._h, self._h, ptr(bgd), ptr(a[0]), ptr(a[1]), ptr(a[2]),
+                                                 ptr(b[0]), ptr(b[1]), W, ptr(score), ptr(loc), ptr(tid)))
+        return score, loc, tid
+
     def download(self):
         scores = np.empty(self.P, np.float32)
         ids = np.empty(self.P, np.int32)

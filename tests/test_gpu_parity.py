@@ -506,6 +506,23 @@ def test_classification_random_vs_oracle(mods, oracle):
                 oracle.compute_classification_E(E, None, flts.copy(), 0, ref[0], ref[1], ref[2], ref[3], bank)
             for a, b in zip(got, ref):
                 assert np.array_equal(a, b), (T, isolated)
+    # the materialised-window entry point agrees with the virtual windows, and the batched corpus loop
+    # with the per-utterance calls
+    utts = [synth.features(rng, T, q) for T in (64, 90, 41)]
+    fl = [np.array([0, 9, 30, 52, 64]), np.array([0, 40, 45, 90]), np.array([0, 20, 41])]
+    for isolated in (False, True):
+        batched = gtrd.get_classify_scores_E(utts, fl, bank, bgd=q, isolated=isolated)
+        for n, (E, f) in enumerate(zip(utts, fl)):
+            z = [np.zeros((1, 4), dt) for dt in (np.float32, np.int16, np.uint16, np.uint16)]
+            fn = oracle.compute_isolated_classification_E if isolated else oracle.compute_classification_E
+            fn(*((E, None, f.copy(), 0, z[0], z[3], z[2], z[1], bank) + ((q,) if isolated else ())))
+            for a, b in zip(batched, z):
+                assert np.array_equal(a[n, :len(f) - 1], b[0, :len(f) - 1]), (isolated, n)
+    ew, ws, we, pad = gtrd.get_isolated_classify_windows(utts[0], None, fl[0].copy(), q, bank)
+    sc, pos, tid = tsr_hip.Bank(bank).classify_float_windows(ew, we.astype(np.int64) - ws)
+    ref = gtrd.get_classify_scores_E(utts[:1], fl[:1], bank, bgd=q, isolated=True)
+    assert np.array_equal(sc, ref[0][0]) and np.array_equal(tid, ref[3][0])
+    assert np.array_equal(ws + pos - pad, ref[1][0])
     # the MFMA scores give the same winners unless two candidates are within the quantisation noise
     E = synth.features(rng, 200, q)
     flts = np.arange(0, 201, 20, dtype=np.int64)
