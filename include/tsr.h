@@ -208,6 +208,25 @@ int tsr_corpus_classify_isolated(tsr_ctx *ctx, const tsr_bank *bank, const tsr_c
                                  const int64_t *real_hi, const int32_t *rows, const int32_t *n_valid,
                                  int64_t W, float *score, int32_t *loc, int32_t *template_id);
 
+/* ---- peak picking on the score rows (roc_functions.py) ----------- */
+/* Score source of the two functions below: `corpus` != NULL -> the scores tsr_corpus_score left on
+ * the device (vals/offsets/N ignored); else host rows vals f32 [offsets[N]], utterance n =
+ * [offsets[n], offsets[n+1]).
+ * tsr_peaks = get_max_above_threshold (roc_functions.py:177-187) for every utterance: with
+ * l = T_n - C0 + 1 the indices t in [1, l-1) where v[t] >= v[t-1], v[t] >= v[t+1] and
+ * v[t] >= threshold (compared in f32), ascending.  counts i64 [N]; utterance n's indices are stored
+ * from times[offsets[n]] on (times i32 [offsets[N]]). */
+int tsr_peaks(tsr_ctx *ctx, const tsr_corpus *corpus, const float *vals, const int64_t *offsets, int64_t N,
+              float threshold, int C0, int64_t *counts, int32_t *times);
+/* get_max_detection_in_syllable_windows (roc_functions.py:88-139), the per-window part: window w is
+ * the slice [starts[w], ends[w]) of row utt[w] of the zero-padded detection array (positions at or
+ * beyond the utterance's T_n read 0, as in the reference's np.zeros rows; the caller clips ends to the
+ * row width); out[w] = the largest inner value of the slice that is >= both its neighbours, -inf if
+ * there is none. */
+int tsr_window_peak_max(tsr_ctx *ctx, const tsr_corpus *corpus, const float *vals, const int64_t *offsets,
+                        int64_t N, const int64_t *utt, const int64_t *starts, const int64_t *ends, int64_t W,
+                        float *out);
+
 /* ---- multi-GPU: utterances shard across ranks, the bank is broadcast once ----- */
 /* One process per GPU.  Rank 0 calls tsr_dist_unique_id and hands the 128 bytes
  * to the other ranks over any host channel; every rank then calls

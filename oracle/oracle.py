@@ -373,3 +373,32 @@ def compute_isolated_classification_E(E, phns, E_flts, utt_id, classify_array, c
                 classify_template_ids[utt_id, phn_id] = filter_id
                 classify_template_lengths[utt_id, phn_id] = len(cur_filt)
                 classify_array[utt_id, phn_id] = v
+
+
+# ---- peak picking, restated from text: roc_functions.py is a Python-2 module with
+# no native part, so these two have no compiled reference behind them ("parity unpinned": the check is
+# HIP kernel vs this NumPy restatement only).
+def get_max_above_threshold(detection_vals, detection_length, threshold, C0):
+    """roc_functions.py:177-187."""
+    l = detection_length - C0 + 1
+    v = np.asarray(detection_vals)
+    if l - 1 <= 1:
+        return np.zeros(0, np.uint16)
+    return np.arange(1, l - 1, dtype=np.uint16)[(v[1:l - 1] >= v[:l - 2]) * (v[1:l - 1] >= v[2:l])
+                                                * (v[1:l - 1] >= np.float32(threshold))]
+
+
+def get_max_detection_in_syllable_windows(detection_array, example_start_end_times, detection_lengths,
+                                          window_start, window_end, return_argsort_idx=False):
+    """roc_functions.py:88-139."""
+    max_detect_vals, utterance_ids = [], []
+    for example_idx, start_end_times in enumerate(example_start_end_times):
+        for start_time, end_time in start_end_times:
+            detect_vals = detection_array[example_idx, max(start_time + window_start, 0):
+                                          min(start_time + window_end, detection_array.shape[1])]
+            maybe = detect_vals[1:-1][(detect_vals[1:-1] >= detect_vals[:-2]) * (detect_vals[1:-1] >= detect_vals[2:])]
+            max_detect_vals.append(maybe.max() if len(maybe) > 0 else -np.inf)
+            utterance_ids.append(example_idx)
+    if return_argsort_idx:
+        return np.sort(max_detect_vals), np.argsort(max_detect_vals), np.array(utterance_ids)
+    return np.sort(max_detect_vals)

@@ -223,3 +223,80 @@ int tsr_launch_isolated_windows(tsr_ctx *ctx, const tsr_bank *bank, const uint8_
     TSR_HIP(hipGetLastError());
     return TSR_OK;
 }
+
+// ---- peak picking on the score rows -------------------------------------------
+namespace {
+// roc_functions.py:177-187 (get_max_above_threshold): for utterance n with T_n scores and
+// l = T_n - C0 + 1, the indices t in [1, l-1) with v[t] >= v[t-1], v[t] >= v[t+1] and
+// v[t] >= threshold, ascending.  One wave per utterance, ballot-ordered compaction; utterance n's
+// indices are written from times[offsets[n]] on, their number to counts[n].
+__global__ __launch_bounds__(kThreads) void peaks_kernel(const float *__restrict__ v, const int64_t *__restrict__ offsets,
+                                                         int64_t N, float threshold, int C0,
+                                                         int64_t *__restrict__ counts, int32_t *__restrict__ times)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int64_t o = offsets[n];
+    const int64_t l = offsets[n + 1] - o - C0 + 1;
+    const float *__restrict__ x = v + o;
+    int64_t cnt = 0;
+    for (int64_t t0 = 1; t0 < l - 1; t0 += 64) {
+        const int64_t t = t0 + lane;
+        bool hit = false;
+        if (t < l - 1) {
+            const float c = x[t];
+            hit = c >= x[t - 1] && c >= x[t + 1] && c >= threshold;
+        }
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+        if (hit) times[o + cnt + __builtin_popcountll(mask & ((1ull << lane) - 1))] = (int32_t)t;
+        cnt += __builtin_popcountll(mask);
+    }
+    if (lane == 0) counts[n] = cnt;
+}
+
+// roc_functions.py:88-139 (get_max_detection_in_syllable_windows): window w is the slice [s, e) of
+// row utt[w] of the zero-padded detection array (values beyond the utterance's T_n scores are 0);
+// among its inner positions that are >= both neighbours inside the slice, the maximum; -inf if none.
+__global__ __launch_bounds__(kThreads) void window_peak_max_kernel(
+    const float *__restrict__ v, const int64_t *__restrict__ offsets, const int64_t *__restrict__ utt,
+    const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t W, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (w >= W) return;
+    const int64_t n = utt[w], o = offsets[n], T = offsets[n + 1] - o;
+    const int64_t s = starts[w], e = ends[w];
+    auto at = [&](int64_t t) { return t < T ? v[o + t] : 0.0f; };
+    float best = -__builtin_inff();
+    for (int64_t t = s + 1 + lane; t < e - 1; t += 64) {
+        const float c = at(t);
+        if (c >= at(t - 1) && c >= at(t + 1)) best = fmaxf(best, c);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) best = fmaxf(best, __shfl_xor(best, off));
+    if (lane == 0) out[w] = best;
+}
+}  // namespace
+
+int tsr_launch_peaks(tsr_ctx *ctx, const float *d_v, const int64_t *d_offsets, int64_t N, float threshold, int C0,
+                     int64_t *d_counts, int32_t *d_times)
+{
+    if (N <= 0) return TSR_OK;
+    const int wpb = kThreads / 64;
+    hipLaunchKernelGGL(peaks_kernel, dim3((unsigned)((N + wpb - 1) / wpb)), dim3(kThreads), 0, ctx->stream, d_v,
+                       d_offsets, N, threshold, C0, d_counts, d_times);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+
+int tsr_launch_window_peak_max(tsr_ctx *ctx, const float *d_v, const int64_t *d_offsets, const int64_t *d_utt,
+                               const int64_t *d_starts, const int64_t *d_ends, int64_t W, float *d_out)
+{
+    if (W <= 0) return TSR_OK;
+    const int wpb = kThreads / 64;
+    hipLaunchKernelGGL(window_peak_max_kernel, dim3((unsigned)((W + wpb - 1) / wpb)), dim3(kThreads), 0, ctx->stream,
+                       d_v, d_offsets, d_utt, d_starts, d_ends, W, d_out);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}

@@ -647,6 +647,80 @@ TSR_API int tsr_corpus_classify_isolated(tsr_ctx *ctx, const tsr_bank *bank, con
     return TSR_OK;
 }
 
+// ---- peak picking on score rows ------------------------------------
+// Both take either host score rows (`vals` f32 [offsets[N]], utterance n = [offsets[n], offsets[n+1]))
+// or, with vals == NULL, the scores a previous tsr_corpus_score left on the device.
+static int peaks_source(tsr_ctx *ctx, const tsr_corpus *cp, const float *vals, const int64_t *offsets, int64_t N,
+                        const float **d_v, const int64_t **d_off, int64_t *total, const char *who)
+{
+    TSR_REQUIRE(ctx && (cp || (vals && offsets)), "%s: need a scored corpus or host score rows", who);
+    TSR_HIP(hipSetDevice(ctx->device));
+    const int64_t *offs = cp ? cp->offsets.data() : offsets;
+    const int64_t n = cp ? cp->N : N;
+    TSR_REQUIRE(n >= 0 && offs[0] == 0, "%s: bad offsets", who);
+    for (int64_t i = 0; i < n; ++i) TSR_REQUIRE(offs[i + 1] >= offs[i], "%s: offsets must not decrease", who);
+    *total = offs[n];
+    void *dO = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX, (size_t)(n + 1) * 8, &dO));
+    TSR_HIP(hipMemcpyAsync(dO, offs, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    *d_off = (const int64_t *)dO;
+    if (cp) {
+        *d_v = cp->d_scores;
+    } else {
+        void *dV = nullptr;
+        TSR_TRY(tsr_scratch(ctx, SLOT_IN, (size_t)std::max<int64_t>(*total, 1) * 4, &dV));
+        if (*total) TSR_HIP(hipMemcpyAsync(dV, vals, (size_t)*total * 4, hipMemcpyHostToDevice, ctx->stream));
+        *d_v = (const float *)dV;
+    }
+    return TSR_OK;
+}
+
+TSR_API int tsr_peaks(tsr_ctx *ctx, const tsr_corpus *cp, const float *vals, const int64_t *offsets, int64_t N,
+                      float threshold, int C0, int64_t *counts, int32_t *times)
+{
+    TSR_REQUIRE(counts && times, "tsr_peaks: null output");
+    const float *d_v;
+    const int64_t *d_off;
+    int64_t total;
+    TSR_TRY(peaks_source(ctx, cp, vals, offsets, N, &d_v, &d_off, &total, "tsr_peaks"));
+    const int64_t n = cp ? cp->N : N;
+    if (n == 0) return TSR_OK;
+    void *dC = nullptr, *dT = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX2, (size_t)n * 8, &dC));
+    TSR_TRY(tsr_scratch(ctx, SLOT_W, (size_t)std::max<int64_t>(total, 1) * 4, &dT));
+    TSR_TRY(tsr_launch_peaks(ctx, d_v, d_off, n, threshold, C0, (int64_t *)dC, (int32_t *)dT));
+    TSR_HIP(hipMemcpyAsync(counts, dC, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (total) TSR_HIP(hipMemcpyAsync(times, dT, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    return TSR_OK;
+}
+
+TSR_API int tsr_window_peak_max(tsr_ctx *ctx, const tsr_corpus *cp, const float *vals, const int64_t *offsets,
+                                int64_t N, const int64_t *utt, const int64_t *starts, const int64_t *ends, int64_t W,
+                                float *out)
+{
+    TSR_REQUIRE(W >= 0 && (W == 0 || (utt && starts && ends && out)), "tsr_window_peak_max: null pointer");
+    const float *d_v;
+    const int64_t *d_off;
+    int64_t total;
+    TSR_TRY(peaks_source(ctx, cp, vals, offsets, N, &d_v, &d_off, &total, "tsr_window_peak_max"));
+    const int64_t n = cp ? cp->N : N;
+    if (W == 0) return TSR_OK;
+    for (int64_t w = 0; w < W; ++w)
+        TSR_REQUIRE(utt[w] >= 0 && utt[w] < n && starts[w] >= 0, "tsr_window_peak_max: window %lld refers to utterance %lld / start %lld", (long long)w, (long long)utt[w], (long long)starts[w]);
+    void *dWn = nullptr, *dR = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX2, (size_t)W * 24, &dWn));
+    TSR_TRY(tsr_scratch(ctx, SLOT_W, (size_t)W * 4, &dR));
+    int64_t *d_utt = (int64_t *)dWn, *d_s = d_utt + W, *d_e = d_s + W;
+    TSR_HIP(hipMemcpyAsync(d_utt, utt, (size_t)W * 8, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(d_s, starts, (size_t)W * 8, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(d_e, ends, (size_t)W * 8, hipMemcpyHostToDevice, ctx->stream));
+    TSR_TRY(tsr_launch_window_peak_max(ctx, d_v, d_off, d_utt, d_s, d_e, W, (float *)dR));
+    TSR_HIP(hipMemcpyAsync(out, dR, (size_t)W * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    return TSR_OK;
+}
+
 // ---- single-utterance drop-ins ----------------------------------------------------
 TSR_API int tsr_detect_u8(tsr_ctx *ctx, const uint8_t *F, int64_t T, int64_t D, const float *LF,
                           int64_t L, float *out)

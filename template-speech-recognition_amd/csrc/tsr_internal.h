@@ -149,6 +149,10 @@ int tsr_launch_float_windows(tsr_ctx *ctx, const tsr_bank *bank, const float *d_
 int tsr_launch_isolated_windows(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *d_X, int Dp, const float *d_bgd,
                                 const int64_t *d_first, const int64_t *d_lo, const int64_t *d_hi,
                                 const int32_t *d_left, int64_t NW, float *d_out);
+int tsr_launch_peaks(tsr_ctx *ctx, const float *d_v, const int64_t *d_offsets, int64_t N, float threshold, int C0,
+                     int64_t *d_counts, int32_t *d_times);
+int tsr_launch_window_peak_max(tsr_ctx *ctx, const float *d_v, const int64_t *d_offsets, const int64_t *d_utt,
+                               const int64_t *d_starts, const int64_t *d_ends, int64_t W, float *d_out);
 // parts_mfma.hip
 int tsr_parts_mfma_prepare(tsr_ctx *ctx, tsr_parts *p, const double *lp, const double *lip);
 void tsr_parts_mfma_free(tsr_parts *p);

@@ -273,6 +273,44 @@ class Corpus:
         return scores, ids
 
 
+def _rows(vals, offsets):
+    vals = np.ascontiguousarray(vals, dtype=np.float32).reshape(-1)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    if offsets.ndim != 1 or offsets.size < 1 or vals.size != int(offsets[-1]):
+        raise ValueError("vals must hold offsets[-1] scores")
+    return vals, offsets
+
+
+def peaks(threshold, C0, corpus=None, vals=None, offsets=None, ctx=None):
+    """get_max_above_threshold (roc_functions.py:177-187) for every utterance, on the scores resident
+    in `corpus` or on host rows (vals, offsets) -> list of ascending index arrays (int32)."""
+    if corpus is not None:
+        c, h, v, o, N = corpus.ctx, corpus._h, None, corpus.offsets, corpus.N
+    else:
+        c = ctx or default_ctx()
+        v, o = _rows(vals, offsets)
+        h, N = None, len(o) - 1
+    counts = np.zeros(N, np.int64)
+    times = np.empty(int(o[-1]), np.int32)
+    check(lib().tsr_peaks(c._h, h, ptr(v), ptr(o), N, float(threshold), int(C0), ptr(counts), ptr(times)))
+    return [times[o[n]:o[n] + counts[n]].copy() for n in range(N)]
+
+
+def window_peak_max(utt, starts, ends, corpus=None, vals=None, offsets=None, ctx=None):
+    """Per-window largest local maximum (roc_functions.py:107-116) -> f32 [W] (-inf where none)."""
+    if corpus is not None:
+        c, h, v, o, N = corpus.ctx, corpus._h, None, corpus.offsets, corpus.N
+    else:
+        c = ctx or default_ctx()
+        v, o = _rows(vals, offsets)
+        h, N = None, len(o) - 1
+    a = [np.ascontiguousarray(x, dtype=np.int64) for x in (utt, starts, ends)]
+    W = a[0].shape[0]
+    out = np.empty(W, np.float32)
+    check(lib().tsr_window_peak_max(c._h, h, ptr(v), ptr(o), N, ptr(a[0]), ptr(a[1]), ptr(a[2]), W, ptr(out)))
+    return out
+
+
 class Parts:
     """Device-resident part models of the patch coder (tsr_parts): logParts /
     logInvParts of get_train_data.PartsParameters, f64 [K, P0, P1, E]."""

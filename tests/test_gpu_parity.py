@@ -548,3 +548,43 @@ def test_isolated_windows_reject_float64_background(mods):
     z = [np.zeros((1, 3), dt) for dt in (np.float32, np.uint16, np.uint16, np.int16)]
     with pytest.raises(ValueError, match="Buffer dtype mismatch, expected 'DTYPE_t' but got 'double'"):
         gtrd._compute_isolated_classification_E(E, None, np.array([0, 20, 41, 60]), 0, z[0], z[1], z[2], z[3], bank, q)
+
+
+# ---- peak picking: HIP kernels vs the NumPy restatement of roc_functions.py ------
+def test_peak_picking(mods, oracle):
+    tsr_hip = mods[3]
+    import template_speech_rec.roc_functions as rf
+    rng = np.random.default_rng(21)
+    lengths = np.array([200, 3, 64, 65, 1, 130, 2, 0, 77])
+    width = int(lengths.max()) + 2
+    det = np.zeros((len(lengths), width), np.float32)
+    for n, T in enumerate(lengths):
+        det[n, :T] = np.round(rng.normal(size=T) * 4) / 4          # quantised: plateaus and exact ties
+    for thr in (-np.inf, -0.5, 0.0, 1.25):
+        for C0 in (1, 8, 33):
+            got = rf.get_peaks_above_threshold(det, lengths, thr, C0)
+            for n, T in enumerate(lengths):
+                want = oracle.get_max_above_threshold(det[n], int(T), thr, C0)
+                assert got[n].dtype == np.uint16 and np.array_equal(got[n], want), (thr, C0, n)
+                if T >= C0 + 2:
+                    assert np.array_equal(rf.get_max_above_threshold(det[n], int(T), thr, C0), want)
+    examples = []
+    for n, T in enumerate(lengths):
+        k = int(rng.integers(0, 5))
+        st = np.sort(rng.integers(0, max(T, 1), size=k))
+        examples.append([(int(s), int(s) + 10) for s in st])
+    for ws, we in ((-7, 8), (0, 3), (-2, 1), (-40, 60), (5, 6)):
+        got = rf.get_max_detection_in_syllable_windows(det, examples, lengths, ws, we, return_argsort_idx=True)
+        want = oracle.get_max_detection_in_syllable_windows(det, examples, lengths, ws, we, return_argsort_idx=True)
+        assert np.array_equal(got[0], np.asarray(want[0], np.float32)) and np.array_equal(got[2], want[2])
+    # on the scores a scoring pass left on the device
+    from tsr_hip import synth
+    c = synth.corpus(8, 40, 90, F=7, E=4, M=3, L=11)
+    corpus = tsr_hip.Corpus(c["feats"], c["offsets"])
+    corpus.score(tsr_hip.Bank(c["bank"]), tsr_hip.TSR_EXACT)
+    s, _ = corpus.download()
+    thr = float(np.median(s))
+    got = tsr_hip.peaks(thr, 11, corpus=corpus)
+    for n in range(40):
+        row = s[c["offsets"][n]:c["offsets"][n + 1]]
+        assert np.array_equal(got[n], oracle.get_max_above_threshold(row, 90, thr, 11))
