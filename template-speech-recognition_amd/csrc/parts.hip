@@ -230,10 +230,10 @@ namespace {
 // K <= 64: the same dilation on 64-bit part masks.  One wave per output frame:
 //   1. the (<= 2*r0+1) source rows of part ids become rows of one-hot masks in LDS (coalesced);
 //   2. lane oj ORs the clipped box of its column (LDS reads only), applies the graph closure in
-//      the reference's order (sequential over the source part, code_parts.pyx:459-503) and parks
-//      the mask in LDS;
-//   3. the lanes write the frame's output row as whole 16-byte chunks (1 byte per (column, part),
-//      zero padding up to Dp_out included) -- no memset beforehand, no scattered byte stores.
+//      the reference's order (sequential over the source part, code_parts.pyx:459-503) and ORs its
+//      K bits into the frame's bit stream in LDS (bit oj*K + k);
+//   3. the lanes expand the stream to bytes and write the frame's output row as whole 16-byte
+//      chunks (zero padding up to Dp_out included) -- no memset beforehand, no scattered byte stores.
 constexpr int kSpreadWaves = 4;
 
 __global__ __launch_bounds__(64 * kSpreadWaves) void spread_mask_kernel(
@@ -245,8 +245,10 @@ __global__ __launch_bounds__(64 * kSpreadWaves) void spread_mask_kernel(
     extern __shared__ __attribute__((aligned(16))) uint8_t sp_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int R = 2 * r0 + 1;
-    uint64_t *bits = reinterpret_cast<uint64_t *>(sp_smem) + (size_t)wave * ((size_t)R * N1 + O1);  // [R][N1]
-    uint64_t *masks = bits + (size_t)R * N1;                                                        // [O1]
+    const size_t per_wave = ((size_t)R * N1 * 8 + ((size_t)(Dp_out >> 5) + 3) * 4 + 7) / 8 * 8;
+    uint64_t *bits = reinterpret_cast<uint64_t *>(sp_smem + (size_t)wave * per_wave);  // [R][N1]
+    uint32_t *stream = reinterpret_cast<uint32_t *>(bits + (size_t)R * N1);  // the row as a bit stream: bit oj*K + k
+    const int nwords = (Dp_out >> 5) + 3;                                     // 1 bit per output byte (+ spill-over)
     const int64_t pf = (int64_t)blockIdx.x * kSpreadWaves + wave;
     const bool on = pf < P_out;
     int lo0 = 0, hi0 = 0;
@@ -259,6 +261,7 @@ __global__ __launch_bounds__(64 * kSpreadWaves) void spread_mask_kernel(
                 const int p = A[(int64_t)x0 * N1 + c];
                 bits[(x0 - lo0) * N1 + c] = p > 0 ? 1ull << (p - 1) : 0ull;
             }
+        for (int w = lane; w < nwords; w += 64) stream[w] = 0;
     }
     __syncthreads();
     if (on)
@@ -271,27 +274,26 @@ __global__ __launch_bounds__(64 * kSpreadWaves) void spread_mask_kernel(
             if (graph_masks)
                 for (int a = 0; a < K; ++a)
                     if ((m >> a) & 1) m |= graph_masks[a];
-            masks[oj] = m;
+            // drop the K bits at bit offset oj*K of the stream (they straddle up to three words)
+            const int off = oj * K, sh = off & 31;
+            const uint64_t lo = m << sh;
+            uint32_t *w = stream + (off >> 5);
+            if ((uint32_t)lo) atomicOr(w, (uint32_t)lo);
+            if ((uint32_t)(lo >> 32)) atomicOr(w + 1, (uint32_t)(lo >> 32));
+            if (sh && (uint32_t)(m >> (64 - sh))) atomicOr(w + 2, (uint32_t)(m >> (64 - sh)));
         }
     __syncthreads();
     if (!on) return;
+    // one stream bit per output byte: a 16-byte chunk is 16 consecutive bits; 4 bits -> 4 bytes by
+    // (nibble * 0x00204081) & 0x01010101 (bit i lands on bit 8 i, the other partial products are masked)
     uint8_t *row = out + pf * Dp_out;
-    const int nbytes = O1 * K;
+    const uint16_t *stream16 = reinterpret_cast<const uint16_t *>(stream);
     for (int ci = lane; ci * 16 < Dp_out; ci += 64) {
-        const int b0 = ci * 16;
-        int oj = b0 / K, kk = b0 - oj * K;
-        uint64_t m = oj < O1 ? masks[oj] : 0ull;
-        uint32_t w[4] = {0, 0, 0, 0};
+        const uint32_t b = stream16[ci];
+        uint32_t w[4];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            if (b0 + t < nbytes) w[t >> 2] |= (uint32_t)((m >> kk) & 1) << (8 * (t & 3));
-            if (++kk == K) {
-                kk = 0;
-                ++oj;
-                m = oj < O1 ? masks[oj] : 0ull;
-            }
-        }
-        *reinterpret_cast<uint4 *>(row + b0) = make_uint4(w[0], w[1], w[2], w[3]);
+        for (int q = 0; q < 4; ++q) w[q] = (((b >> (4 * q)) & 0xfu) * 0x00204081u) & 0x01010101u;
+        *reinterpret_cast<uint4 *>(row + ci * 16) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 }  // namespace
@@ -306,7 +308,8 @@ int tsr_launch_spread_stream(tsr_ctx *ctx, const int32_t *d_A, int64_t N1, int r
     (void)g0;
     const int64_t n = P_out * O1;
     if (n <= 0) return TSR_OK;
-    const size_t lds = (size_t)kSpreadWaves * ((size_t)(2 * r0 + 1) * N1 + O1) * 8;
+    const size_t per_wave = ((size_t)(2 * r0 + 1) * N1 * 8 + ((size_t)(Dp_out >> 5) + 3) * 4 + 7) / 8 * 8;
+    const size_t lds = (size_t)kSpreadWaves * per_wave;
     if (K <= 64 && lds <= 48 * 1024 && Dp_out % 16 == 0) {
         hipLaunchKernelGGL(spread_mask_kernel, dim3((unsigned)((P_out + kSpreadWaves - 1) / kSpreadWaves)),
                            dim3(64 * kSpreadWaves), lds, ctx->stream, d_A, (int)N1, r0, r1, (int)K, g1, (int)O1, P_out,
