@@ -150,9 +150,14 @@ template <> struct RingT<2> { using type = int; };
 // int32 ring; 3: 23-bit fixed point, int64 ring); FLAT: LDS row stride == resident row stride.
 // MODE: 0 = max score + template id per frame, 1 = every template's score, 2 = partial raw
 // scores per template fragment (several column groups; frag_epilogue_kernel finishes them).
-template <int NKB, int NL, bool FLAT, int MODE>
-__global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a)
+// CPW: column tiles per wave.  1: eight waves of 32 columns, two per SIMD.  2: four waves of 64
+// columns, ONE per SIMD with the whole 512-register file: every A fragment read from LDS feeds
+// twice the MFMAs, and all of the wave's other work is issued in the shadow of its own MFMAs.
+template <int NKB, int NL, bool FLAT, int MODE, int CPW>
+__global__ __launch_bounds__(kThreads / CPW, CPW == 2 ? 1 : 2) void fast_bank_kernel(const FastArgs a)
 {
+    constexpr int kW = kWaves / CPW;  // waves per workgroup
+    constexpr int kT = kW * 64;
     using ring_t = typename RingT<NL>::type;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
@@ -178,32 +183,36 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
     int *uend_ring = reinterpret_cast<int *>(meta + kMaxSlots);  // utt_end of the frames in flight
     unsigned long long *maxring = reinterpret_cast<unsigned long long *>(uend_ring + a.ring + 64);
     ring_t *ring = reinterpret_cast<ring_t *>(maxring + a.ring);
-    for (int i = tid; i < a.ring; i += kThreads) maxring[i] = 0;
+    for (int i = tid; i < a.ring; i += kT) maxring[i] = 0;
     const int ring_mask = a.ring - 1;
     const int rstride = a.ring + 33;  // odd: a column of the ring hits distinct banks
     const int dummy = nslots * rstride;  // out-of-range emissions land in this spare row
-    for (int i = tid; i < (nslots + 1) * rstride; i += kThreads) ring[i] = 0;
+    for (int i = tid; i < (nslots + 1) * rstride; i += kT) ring[i] = 0;
     if (tid < nslots) meta[tid] = a.slots[cg * kMaxSlots + tid];
 
     // ---- this wave's role and its register-stationary limb fragments --------------------
-    const int ct = wave / a.KS, ks = wave - ct * a.KS;
-    const int coltile = cg * a.CT + ct;
-    i32x4 b[NKB][NL];
-    {
-        const i32x4 *wl = a.Wl + ((size_t)(coltile * a.KS + ks) * NKB * NL) * 64 + lane;
+    const int half = lane >> 5;
+    i32x4 b[CPW][NKB][NL];
+    int kl[CPW];           // frame (relative to the tile's first row) of accumulator row 0
+    ring_t *my_row[CPW];
+    bool real_cols = true;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int coltile = cg * a.CT + wave * CPW + c;
+        const i32x4 *wl = a.Wl + ((size_t)coltile * NKB * NL) * 64 + lane;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int l = 0; l < NL; ++l) b[kb][l] = wl[(kb * NL + l) * 64];
+            for (int l = 0; l < NL; ++l) b[c][kb][l] = wl[(kb * NL + l) * 64];
+        const int col = coltile * 32 + (lane & 31);
+        const int slot = a.col_slot[col];
+        // padding columns get a tap index that pushes every target frame out of range
+        const int tau = slot >= 0 ? a.col_tau[col] : (1 << 28);
+        my_row[c] = ring + (slot >= 0 ? slot : nslots) * rstride;
+        kl[c] = 4 * half - tau;
+        real_cols = real_cols && slot >= 0;
     }
-    const int col = coltile * 32 + (lane & 31);
-    const int slot = a.col_slot[col];
-    // padding columns get a tap index that pushes every target frame out of range
-    const int tau = slot >= 0 ? a.col_tau[col] : (1 << 28);
-    const int half = lane >> 5;
-    ring_t *const my_row = ring + (slot >= 0 ? slot : nslots) * rstride;
     ring_t *const dummy_row = ring + dummy;
-    const int kl = 4 * half - tau;  // frame (relative to the tile's first row) of accumulator row 0
 
     // ---- frame tiles: tile t = rows [o0 + 32 t, +32), copied by LDS-DMA --------------------
     // one DMA instruction moves 1 KiB (64 lanes x 16 B); wave w issues pieces w, w+8, ...
@@ -220,29 +229,33 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
         return row * a.Dp + min(c16, src_slots - 1) * 16;
     };
     // (kept in registers only when there are registers to spare)
-    const int src_off0 = NL == 2 ? piece_src_off(wave) : 0, src_off1 = NL == 2 ? piece_src_off(wave + kWaves) : 0;
+    constexpr int NP = 2 * CPW;  // DMA pieces per wave whose source offsets stay in registers
+    int src_off[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) src_off[i] = NL == 2 ? piece_src_off(wave + i * kW) : 0;
     const uint8_t *const seg_src = a.X + (int64_t)o0 * a.Dp;
     const int tile_src_bytes = 32 * a.Dp;
     auto stage = [&](int t, unsigned dst) {
         if (TSR_ABL & 8) return;
         const uint8_t *src_tile = seg_src + (int64_t)t * tile_src_bytes;
-        if (wave < n_pieces) lds_dma16(src_tile + (NL == 2 ? src_off0 : piece_src_off(wave)), dst + wave * 1024);
-        if (wave + kWaves < n_pieces)
-            lds_dma16(src_tile + (NL == 2 ? src_off1 : piece_src_off(wave + kWaves)), dst + (wave + kWaves) * 1024);
-        for (int pc = wave + 2 * kWaves; pc < n_pieces; pc += kWaves)  // wide rows only
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            if (wave + i * kW < n_pieces)
+                lds_dma16(src_tile + (NL == 2 ? src_off[i] : piece_src_off(wave + i * kW)), dst + (wave + i * kW) * 1024);
+        for (int pc = wave + NP * kW; pc < n_pieces; pc += kW)  // wide rows only
             lds_dma16(src_tile + piece_src_off(pc), dst + pc * 1024);
         // the utt_end values of the tile's 32 frames ride along (4-byte DMA, one wave): the
         // finishing pass must not issue register loads, or hipcc drains the tile DMA early
-        if (wave == kWaves - 1 && lane < 32)
+        if (wave == kW - 1 && lane < 32)
             lds_dma4(a.utt_end + (int64_t)o0 + 32 * (int64_t)t + lane,
                      __builtin_amdgcn_readfirstlane(lds_addr(uend_ring + ((32 * t) & ring_mask))));
     };
 
     // A-fragment address of this lane: row (lane & 31), K-group (lane >> 5) of its K-slice
-    const int a_off = (lane & 31) * a.SB + half * 16 + ks * (NKB * 32);
+    const int a_off = (lane & 31) * a.SB + half * 16;
 
     // ---- finishing pass -----------------------------------------------------------------------
-    // Phase AB (every wave, its own slots: s = wave + 16 j + 8 half; lane&31 is the frame):
+    // Phase AB (every wave, its own slots: s = wave + kW (2 j + half); lane&31 is the frame):
     // read and reset the ring cell (plus its overflow cell when this tile owns them),
     // integer -> f32 score, zero tail, + c_m.  The max / first arg-max over templates is
     // taken by the LDS: one ds_max_u64 per (frame, slot) of the key
@@ -257,7 +270,7 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
         int uend;
     };
     auto fin_a = [&](int f, int j, FinA &fa) {
-        const int s = wave + 16 * j + 8 * half;
+        const int s = wave + kW * (2 * j + half);
         const int ridx = (f * 32 + (lane & 31)) & ring_mask;
         ring_t *cell = ring + min(s, nslots) * rstride + ridx;  // spare row when s is past the end
         fa.q = *cell;
@@ -270,7 +283,7 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
         fa.uend = uend_ring[ridx];
     };
     auto fin_b = [&](int f, int j, const FinA &fa) {
-        const int s = wave + 16 * j + 8 * half;
+        const int s = wave + kW * (2 * j + half);
         const int prel = f * 32 + (lane & 31);
         const int ridx = prel & ring_mask;
         const SlotMeta sm = fa.sm;
@@ -325,7 +338,7 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
         const int val = half == 0 ? (int)u : (int)~(unsigned)key;
         if (prel < nOut) *dst = val;
     };
-    const int njs = (nslots - wave + 15) / 16;  // slot pairs this wave walks (wave-uniform)
+    const int njs = (nslots - wave + 2 * kW - 1) / (2 * kW);  // slot pairs this wave walks (wave-uniform)
 
     // ---- the pipelined tile loop ----------------------------------------------------------
     // Iteration t (one barrier, in the MIDDLE of the tile):
@@ -351,7 +364,7 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
     const int lag = a.lag + 2;
     // a wave whose 32 columns are all real taps can skip the range check on tiles whose
     // targets [32 te - (Lmax-1), 32 te + 35] all lie inside the segment's outputs
-    const bool no_pad = __all(slot >= 0);
+    const bool no_pad = __all(real_cols);
     const int lmax1 = a.lmax1;
     i32x4 aq[PF];
 
@@ -376,18 +389,25 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
             acc[0][r] = x;
         }
     };
-    auto tile_iter = [&](int t, const i32x16 (&pacc)[NL], i32x16 (&acc)[NL], bool do_emit, bool interior,
+    auto tile_iter = [&](int t, const i32x16 (&pacc)[CPW][NL], i32x16 (&acc)[CPW][NL], bool do_emit, bool interior,
                          int fin) {
 #pragma unroll
-        for (int l = 0; l < NL; ++l) acc[l] = (i32x16){};
+        for (int c = 0; c < CPW; ++c)
+#pragma unroll
+            for (int l = 0; l < NL; ++l) acc[c][l] = (i32x16){};
         const unsigned x_nxt = xnext(x_cur);
         const uint8_t *xa = lds_ptr(x_cur) + a_off, *xn = lds_ptr(x_nxt) + a_off;
-        const int first = kl + 32 * (t - 1);  // target frame of accumulator row 0 (tile t-1)
-        ring_t *const cell0 = my_row + (first & ring_mask);
-        ring_t *const dcell0 = dummy_row + (first & ring_mask);
+        int first[CPW];  // target frame of accumulator row 0 (tile t-1)
+        ring_t *cell0[CPW], *dcell0[CPW];
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            first[c] = kl[c] + 32 * (t - 1);
+            cell0[c] = my_row[c] + (first[c] & ring_mask);
+            dcell0[c] = dummy_row + (first[c] & ring_mask);
+        }
         FinA fa = {};
         unsigned long long ckey = 0;
-        const bool c_wave = fin >= 1 && wave == ((fin - 1) & (kWaves - 1));
+        const bool c_wave = fin >= 1 && wave == ((fin - 1) & (kW - 1));
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             if (kb == H) {
@@ -403,20 +423,23 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
             const int nk = kb + PF;
             aq[PF - 1] = *reinterpret_cast<const i32x4 *>(nk < NKB ? xa + nk * 32 : xn + (nk - NKB) * 32);
             if (TSR_ABL & 2) {
-                asm volatile("" ::"v"(av), "v"(b[kb][0]), "v"(b[kb][NL - 1]));
+                asm volatile("" ::"v"(av), "v"(b[0][kb][0]), "v"(b[CPW - 1][kb][NL - 1]));
             } else {
 #pragma unroll
-                for (int l = 0; l < NL; ++l)
-                    acc[l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b[kb][l], acc[l], 0, 0, 0);
+                for (int c = 0; c < CPW; ++c)
+#pragma unroll
+                    for (int l = 0; l < NL; ++l)
+                        acc[c][l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b[c][kb][l], acc[c][l], 0, 0, 0);
             }
             if (do_emit && !(TSR_ABL & 1)) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (r * NKB / 16 != kb) continue;  // compile-time after unrolling
+                for (int e = 0; e < 16 * CPW; ++e) {
+                    if (e * NKB / (16 * CPW) != kb) continue;  // compile-time after unrolling
+                    const int ci = e >> 4, r = e & 15;
                     const int c = (r & 3) + 8 * (r >> 2);
-                    ring_t *cell = cell0 + c;
-                    if (!interior) cell = ((unsigned)(first + c) < (unsigned)nOut) ? cell : dcell0 + c;
-                    const int vr = combine(pacc, r);
+                    ring_t *cell = cell0[ci] + c;
+                    if (!interior) cell = ((unsigned)(first[ci] + c) < (unsigned)nOut) ? cell : dcell0[ci] + c;
+                    const int vr = combine(pacc[ci], r);
                     if (NL == 2)
                         atomicAdd(reinterpret_cast<unsigned int *>(cell), (unsigned int)vr);
                     else
@@ -435,11 +458,14 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (TSR_ABL & 3) {
 #pragma unroll
-            for (int l = 0; l < NL; ++l) asm volatile("" : "+v"(acc[l]));
+        for (int c = 0; c < CPW; ++c) {
+            if (TSR_ABL & 3) {
+#pragma unroll
+                for (int l = 0; l < NL; ++l) asm volatile("" : "+v"(acc[c][l]));
+            }
+            fold(acc[c]);
         }
-        fold(acc);
         x_cur = x_nxt;
     };
 
@@ -454,26 +480,37 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
     typedef __attribute__((address_space(3))) unsigned long long lds_u64;
     typedef __attribute__((address_space(3))) const i32x4 lds_frag;
     const int lane31 = lane & 31;
-    const int my_s = wave + 8 * half;  // the slot this lane finishes
-    const bool s_ok = my_s < nslots;
-    const SlotMeta my_sm = a.slots[cg * kMaxSlots + min(my_s, kMaxSlots - 1)];
-    const unsigned st_fin_row = lds_addr(ring + (s_ok ? my_s : nslots) * rstride + lane31);
+    constexpr int NJ = CPW;  // slots this lane finishes per tile: s_j = wave + kW (2 j + half)
+    bool s_ok[NJ];
+    SlotMeta my_sm[NJ];
+    unsigned st_fin_row[NJ], st_key_lo[NJ], st_emit_row[CPW];
+    int st_pL0[NJ];  // (frame + L) of this lane's frame in tile 0
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int my_s = wave + kW * (2 * j + half);
+        s_ok[j] = my_s < nslots;
+        my_sm[j] = a.slots[cg * kMaxSlots + min(my_s, kMaxSlots - 1)];
+        st_fin_row[j] = lds_addr(ring + (s_ok[j] ? my_s : nslots) * rstride + lane31);
+        st_pL0[j] = o0 + lane31 + my_sm[j].L;
+        st_key_lo[j] = s_ok[j] ? (unsigned)~my_sm[j].tf : 0u;
+    }
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) st_emit_row[c] = lds_addr(my_row[c]);
     const unsigned st_uend = lds_addr(uend_ring + lane31);
     const unsigned st_max = lds_addr(maxring + lane31);
-    const unsigned st_emit_row = lds_addr(my_row);
-    const int st_pL0 = o0 + lane31 + my_sm.L;  // (frame + L) of this lane's frame in tile 0
-    const unsigned st_key_lo = s_ok ? (unsigned)~my_sm.tf : 0u;
     int *const st_out = (half == 0 ? reinterpret_cast<int *>(a.scores) : a.ids) + o0 + lane31;
     const unsigned st_a_off = (unsigned)a_off;
-    const bool st_p0 = wave < n_pieces, st_p1 = wave + kWaves < n_pieces && n_pieces <= 2 * kWaves;
-    const bool st_ok = MODE == 0 && NL == 2 && nslots <= 16 && n_pieces <= 2 * kWaves;
+    const bool st_ok = MODE == 0 && NL == 2 && nslots <= 2 * kW * NJ && n_pieces <= NP * kW;
 #ifdef TSR_STAMP
     unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0}, st_last = 0;
 #endif
-    const uint8_t *st_src0 = nullptr, *st_src1 = nullptr;  // set where the steady range is known
+    const uint8_t *st_src[NP];  // set where the steady range is known
     const int32_t *st_usrc = nullptr;
     unsigned st_udst0 = 0;
-    auto steady_iter = [&](int t, const i32x16 (&pacc)[NL], i32x16 (&acc)[NL]) {
+    // finishing steps of the steady iteration: phase A of slot j, phase B two steps later, phase C
+    // (read, then decode + store) behind them; everything clamped into the tile's K-block steps
+    auto kclamp = [](int k) constexpr { return k < NKB ? k : NKB - 1; };
+    auto steady_iter = [&](int t, const i32x16 (&pacc)[CPW][NL], i32x16 (&acc)[CPW][NL]) {
 #ifdef TSR_STAMP
         {
             unsigned long long _t;
@@ -483,15 +520,20 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
         }
 #endif
 #pragma unroll
-        for (int l = 0; l < NL; ++l) acc[l] = (i32x16){};
+        for (int c = 0; c < CPW; ++c)
+#pragma unroll
+            for (int l = 0; l < NL; ++l) acc[c][l] = (i32x16){};
         const unsigned x_nxt = xnext(x_cur);
         const unsigned xa = x_cur + st_a_off, xn = x_nxt + st_a_off;
         const int f = t - lag;                                     // phases A/B; phase C does f-1
         const unsigned fb4 = (unsigned)((32 * f) & ring_mask) * 4u;        // byte offset of tile f in a ring row
         const unsigned fc8 = (unsigned)((32 * (f - 1)) & ring_mask) * 8u;  // ... of tile f-1 in the key ring
-        const unsigned cell0 = st_emit_row + (unsigned)((kl + 32 * (t - 1)) & ring_mask) * (unsigned)sizeof(ring_t);
-        const bool c_wave = wave == ((f - 1) & (kWaves - 1));
-        ring_t fq = 0;
+        unsigned cell0[CPW];
+#pragma unroll
+        for (int c = 0; c < CPW; ++c)
+            cell0[c] = st_emit_row[c] + (unsigned)((kl[c] + 32 * (t - 1)) & ring_mask) * (unsigned)sizeof(ring_t);
+        const bool c_wave = wave == ((f - 1) & (kW - 1));
+        ring_t fq[NJ];
         int fuend = 0;
         unsigned long long ckey = 0;
 #pragma unroll
@@ -504,12 +546,13 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
                 TSR_STAMP_AT(2)  // barrier
                 // DMA of tile t+2: per-lane source pointers advance by one tile per iteration
                 const unsigned dst = xnext(x_nxt);
-                if (st_p0) lds_dma16(st_src0, dst + wave * 1024);
-                if (st_p1) lds_dma16(st_src1, dst + (wave + kWaves) * 1024);
-                if (wave == kWaves - 1 && lane < 32)
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    if (wave + i * kW < n_pieces) lds_dma16(st_src[i], dst + (wave + i * kW) * 1024);
+                    st_src[i] += tile_src_bytes;
+                }
+                if (wave == kW - 1 && lane < 32)
                     lds_dma4(st_usrc, st_udst0 + (unsigned)((32 * (t + 2)) & ring_mask) * 4u);
-                st_src0 += tile_src_bytes;
-                st_src1 += tile_src_bytes;
                 st_usrc += 32;
                 TSR_STAMP_AT(3)  // DMA issue
             }
@@ -518,25 +561,30 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
             for (int i = 0; i + 1 < PF; ++i) aq[i] = aq[i + 1];
             const int nk = kb + PF;
             aq[PF - 1] = *(lds_frag *)(size_t)(nk < NKB ? xa + nk * 32 : xn + (nk - NKB) * 32);
-            if (kb == H) {  // finishing phase A: this lane's cell of tile f, reset; utt_end
-                lds_ring *cell = (lds_ring *)(size_t)(st_fin_row + fb4 * (unsigned)(sizeof(ring_t) / 4));
-                fq = *cell;
-                *cell = 0;
-                if (fb4 == 0) {  // wave-uniform: tile f owns the overflow cells
-                    fq += cell[a.ring];
-                    cell[a.ring] = 0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                if (kb == kclamp(H + j)) {  // finishing phase A: this lane's cell of tile f, reset; utt_end
+                    lds_ring *cell = (lds_ring *)(size_t)(st_fin_row[j] + fb4 * (unsigned)(sizeof(ring_t) / 4));
+                    fq[j] = *cell;
+                    *cell = 0;
+                    if (fb4 == 0) {  // wave-uniform: tile f owns the overflow cells
+                        fq[j] += cell[a.ring];
+                        cell[a.ring] = 0;
+                    }
+                    if (j == 0) fuend = *(lds_i32 *)(size_t)(st_uend + fb4);
                 }
-                fuend = *(lds_i32 *)(size_t)(st_uend + fb4);
-            }
 #pragma unroll
-            for (int l = 0; l < NL; ++l)
-                acc[l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b[kb][l], acc[l], 0, 0, 0);
+            for (int c = 0; c < CPW; ++c)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (r * NKB / 16 != kb) continue;  // compile-time after unrolling
+                for (int l = 0; l < NL; ++l)
+                    acc[c][l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, b[c][kb][l], acc[c][l], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 16 * CPW; ++e) {
+                if (e * NKB / (16 * CPW) != kb) continue;  // compile-time after unrolling
+                const int ci = e >> 4, r = e & 15;
                 const int c = (r & 3) + 8 * (r >> 2);
-                lds_ring *cell = (lds_ring *)(size_t)cell0 + c;
-                const int vr = combine(pacc, r);
+                lds_ring *cell = (lds_ring *)(size_t)cell0[ci] + c;
+                const int vr = combine(pacc[ci], r);
                 if (NL == 2)
                     __hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned int *)cell, (unsigned int)vr,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -544,36 +592,50 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
                     __hip_atomic_fetch_add((lds_u64 *)cell, (unsigned long long)(long long)vr, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            if (kb == ((H + 2 < NKB) ? H + 2 : NKB - 1)) {  // finishing phase B
-                float x;
-                if (NL == 2) {
-                    x = (float)fq * my_sm.inv_scale;
-                } else {
-                    const long long qq = fq;
-                    x = __builtin_fmaf((float)(int)(qq >> 24), 16777216.0f, (float)((unsigned)qq & 0xffffffu)) *
-                        my_sm.inv_scale;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                if (kb == kclamp(H + 2 + j)) {  // finishing phase B
+                    float x;
+                    if (NL == 2) {
+                        x = (float)fq[j] * my_sm[j].inv_scale;
+                    } else {
+                        const long long qq = fq[j];
+                        x = __builtin_fmaf((float)(int)(qq >> 24), 16777216.0f, (float)((unsigned)qq & 0xffffffu)) *
+                            my_sm[j].inv_scale;
+                    }
+                    const float raw = (st_pL0[j] + 32 * f <= fuend) ? x : 0.0f;  // zero tail
+                    const float sc = raw + my_sm[j].cf;
+                    unsigned u = __builtin_bit_cast(unsigned, sc);
+                    u ^= (unsigned)((int)u >> 31) | 0x80000000u;
+                    const unsigned long long key = ((unsigned long long)(s_ok[j] ? u : 0u) << 32) | st_key_lo[j];
+                    __hip_atomic_fetch_max((lds_u64 *)(size_t)(st_max + fb4 * 2u), key, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                const float raw = (st_pL0 + 32 * f <= fuend) ? x : 0.0f;  // zero tail
-                const float sc = raw + my_sm.cf;
-                unsigned u = __builtin_bit_cast(unsigned, sc);
-                u ^= (unsigned)((int)u >> 31) | 0x80000000u;
-                const unsigned long long key = ((unsigned long long)(s_ok ? u : 0u) << 32) | st_key_lo;
-                __hip_atomic_fetch_max((lds_u64 *)(size_t)(st_max + fb4 * 2u), key, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            if (kb == ((H + 3 < NKB) ? H + 3 : NKB - 1) && c_wave) {  // phase C: read + reset the keys
+            if (kb == kclamp(H + 2 + NJ) && c_wave) {  // phase C: read + reset the keys
                 lds_u64 *kc = (lds_u64 *)(size_t)(st_max + fc8);
                 ckey = *kc;
                 *kc = 0;  // (both halves read before either write: LDS ops of a wave are in order)
             }
-            if (kb == ((H + 4 < NKB) ? H + 4 : NKB - 1) && c_wave) {  // phase C: decode + store
+            if (kb == kclamp(H + 3 + NJ) && c_wave) {  // phase C: decode + store
                 unsigned u = (unsigned)(ckey >> 32);
                 u ^= (~(unsigned)((int)u >> 31)) | 0x80000000u;
                 st_out[32 * (f - 1)] = half == 0 ? (int)u : (int)~(unsigned)ckey;
             }
+            if (CPW == 2) {
+                // one wave per SIMD: nothing else fills the gap behind an MFMA, so the step's other
+                // instructions are dealt out between its four MFMAs (in-order issue would otherwise
+                // park the wave on the busy matrix pipe with all of them still to come)
+#pragma unroll
+                for (int i = 0; i < CPW * NL; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x080, 2, 0);  // LDS
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        fold(acc);
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) fold(acc[c]);
         x_cur = x_nxt;
         TSR_STAMP_AT(4)  // second half: steps H..NKB-1 + combine
     };
@@ -592,14 +654,16 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
     if (!st_ok || !no_pad) ts1 = ts0;
     while (ts1 > ts0 && !(32 * (ts1 - 2) + 35 < nOut && 32 * (ts1 - 1 - lag) <= nOut)) --ts1;
     // DMA source pointers of the first steady iteration (tile ts0 + 2)
-    st_src0 = seg_src + (int64_t)(ts0 + 2) * tile_src_bytes + src_off0;
-    st_src1 = seg_src + (int64_t)(ts0 + 2) * tile_src_bytes + src_off1;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) st_src[i] = seg_src + (int64_t)(ts0 + 2) * tile_src_bytes + src_off[i];
     st_usrc = a.utt_end + (int64_t)o0 + 32 * (int64_t)(ts0 + 2) + lane;
     st_udst0 = __builtin_amdgcn_readfirstlane(lds_addr(uend_ring));
-    i32x16 accA[NL], accB[NL];
+    i32x16 accA[CPW][NL], accB[CPW][NL];
 #pragma unroll
-    for (int l = 0; l < NL; ++l) accA[l] = (i32x16){};
-    auto one_iter = [&](int t, const i32x16 (&pacc)[NL], i32x16 (&acc)[NL]) {
+    for (int c = 0; c < CPW; ++c)
+#pragma unroll
+        for (int l = 0; l < NL; ++l) accA[c][l] = (i32x16){};
+    auto one_iter = [&](int t, const i32x16 (&pacc)[CPW][NL], i32x16 (&acc)[CPW][NL]) {
         const bool interior = no_pad && 32 * (t - 1) >= lmax1 && 32 * (t - 1) + 35 < nOut;
         if (t >= ts0 && t < ts1)
             steady_iter(t, pacc, acc);
@@ -609,18 +673,22 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
             tile_iter(t, pacc, acc, t > 0, false, t - lag);
     };
     // the last tile's sums go through the skew reduction after the loop (nothing left to overlap)
-    auto emit_last = [&](const i32x16 (&pacc)[NL]) {
+    auto emit_last = [&](const i32x16 (&pacc)[CPW][NL]) {
         if (TSR_ABL & 1) return;
-        const int first = kl + 32 * (nT - 1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int c = (r & 3) + 8 * (r >> 2);
-            ring_t *cell = (((unsigned)(first + c) < (unsigned)nOut) ? my_row : dummy_row) + (first & ring_mask) + c;
-            const int vr = combine(pacc, r);
-            if (NL == 2)
-                atomicAdd(reinterpret_cast<unsigned int *>(cell), (unsigned int)vr);
-            else
-                atomicAdd(reinterpret_cast<unsigned long long *>(cell), (unsigned long long)(long long)vr);
+        for (int ci = 0; ci < CPW; ++ci) {
+            const int first = kl[ci] + 32 * (nT - 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = (r & 3) + 8 * (r >> 2);
+                ring_t *cell =
+                    (((unsigned)(first + c) < (unsigned)nOut) ? my_row[ci] : dummy_row) + (first & ring_mask) + c;
+                const int vr = combine(pacc[ci], r);
+                if (NL == 2)
+                    atomicAdd(reinterpret_cast<unsigned int *>(cell), (unsigned int)vr);
+                else
+                    atomicAdd(reinterpret_cast<unsigned long long *>(cell), (unsigned long long)(long long)vr);
+            }
         }
     };
     int t = 0;
@@ -648,7 +716,7 @@ __global__ __launch_bounds__(kThreads, 2) void fast_bank_kernel(const FastArgs a
     __syncthreads();
     if (!(TSR_ABL & 4))
         for (int f = max(f0 - 1, 0); f < nF; ++f)  // tile f0-1 still awaits its phase C
-            if (wave == (f & (kWaves - 1))) fin_c_store(f, fin_c_read(f));
+            if (wave == (f & (kW - 1))) fin_c_store(f, fin_c_read(f));
 }
 
 // (G > 1) sum the fragments of every template, then the reference epilogue.
@@ -699,15 +767,34 @@ int upload(tsr_ctx *ctx, T **dptr, const std::vector<T> &v)
     return TSR_OK;
 }
 
-template <int NKB, int NL, bool FLAT, int MODE>
-int launch4(tsr_ctx *ctx, const FastArgs &args, int grid, size_t lds)
+template <int NKB, int NL, bool FLAT, int MODE, int CPW>
+int launch5(tsr_ctx *ctx, const FastArgs &args, int grid, size_t lds)
 {
-    TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fast_bank_kernel<NKB, NL, FLAT, MODE>),
+    TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fast_bank_kernel<NKB, NL, FLAT, MODE, CPW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((fast_bank_kernel<NKB, NL, FLAT, MODE>), dim3(grid), dim3(kThreads), lds,
+    hipLaunchKernelGGL((fast_bank_kernel<NKB, NL, FLAT, MODE, CPW>), dim3(grid), dim3(kThreads / CPW), lds,
                        ctx->stream, args);
     TSR_HIP(hipGetLastError());
     return TSR_OK;
+}
+
+// CPW = 1 (eight waves of one column tile, two per SIMD) is what ships.  CPW = 2 -- four waves of
+// two column tiles, one per SIMD -- passes every test but is slower on MI355X (config 2: 47 us vs
+// 36.5: with nothing else on the SIMD every LDS wait of the finishing pass and every DMA issue
+// stalls the matrix pipe); build with -DTSR_CPW2 and run with TSR_CPW=2 to try it.
+template <int NKB, int NL, bool FLAT, int MODE>
+int launch4(tsr_ctx *ctx, const FastArgs &args, int grid, size_t lds)
+{
+#ifdef TSR_CPW2
+    if constexpr (NL == 2) {
+        static const bool wide = [] {
+            const char *e = getenv("TSR_CPW");
+            return e && e[0] == '2';
+        }();
+        if (wide) return launch5<NKB, NL, FLAT, MODE, 2>(ctx, args, grid, lds);
+    }
+#endif
+    return launch5<NKB, NL, FLAT, MODE, 1>(ctx, args, grid, lds);
 }
 
 template <int NKB, int NL, bool FLAT>
