@@ -147,15 +147,43 @@ def main():
 
     # ---- data: every rank its own utterances, one bank for all ----------------------
     corpus = synth.corpus(2 + 1000 * rank, **CFG)
+    bank_bcast = "none (single GPU)"
     if dist is not None:
         from tsr_hip import dist as tdist
-        ctx.dist_init(tdist.exchange_unique_id(dist, tsr_hip.unique_id), world, rank)
+        real_bank = corpus["bank"]
         if rank != 0:  # same geometry, weights to be overwritten by rank 0's
             corpus["bank"] = tdist.placeholder_bank([W.shape[0] for W, _ in corpus["bank"]],
                                                     corpus["bank"][0][0].shape[1:])
-    bank = tsr_hip.Bank(corpus["bank"], ctx=ctx)
-    if dist is not None:
-        bank.broadcast(0)  # RCCL over xGMI; the only collective on this path
+
+        def all_ok(flag):
+            return tdist.max_over_ranks(dist, 0.0 if flag else 1.0)[0] == 0.0
+
+        err = ""
+        try:
+            ctx.dist_init(tdist.exchange_unique_id(dist, tsr_hip.unique_id), world, rank)
+        except tsr_hip.TsrError as e:
+            err = str(e)
+        rccl = all_ok(not err)
+        bank = tsr_hip.Bank(corpus["bank"], ctx=ctx)
+        if rccl:
+            try:
+                bank.broadcast(0)  # RCCL over xGMI; the only collective on this path
+            except tsr_hip.TsrError as e:
+                err = str(e)
+            rccl = all_ok(not err)
+        if rccl:
+            bank_bcast = "rccl"
+        else:
+            # RCCL unusable on this node: hand the bank over the host control plane instead so that
+            # the scaling run still measures the (collective-free) data path; say so in the JSON
+            box = [real_bank if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            corpus["bank"] = box[0]
+            bank = tsr_hip.Bank(corpus["bank"], ctx=ctx)
+            bank_bcast = "gloo fallback (RCCL failed%s)" % ((": " + err[:120]) if err else " on another rank")
+        del real_bank
+    else:
+        bank = tsr_hip.Bank(corpus["bank"], ctx=ctx)
     dev_corpus = tsr_hip.Corpus(corpus["feats"], corpus["offsets"], ctx=ctx)
     if args.mode == "auto":  # the MFMA path when this build has it, else the exact VALU path
         try:
@@ -240,7 +268,8 @@ def main():
             "config": {"workload": "config 2: %d utterances x %d frames x D=%d binary features, "
                                    "%d-template bank, L=%d, per GPU; max-score + template id per frame"
                                    % (CFG["N"], CFG["T"], CFG["F"] * CFG["E"], CFG["M"], CFG["L"]),
-                       "mode": args.mode, "frames_per_gpu": frames, "parallelism": "utterance-sharded x%d" % world},
+                       "mode": args.mode, "frames_per_gpu": frames, "parallelism": "utterance-sharded x%d" % world,
+                       "bank_broadcast": bank_bcast},
             "roofline": roofline,
         }
         out["config"]["window_templates_per_s"] = (CFG["N"] * CFG["M"] * (CFG["T"] - CFG["L"] + 1)
