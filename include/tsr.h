@@ -227,6 +227,20 @@ int tsr_window_peak_max(tsr_ctx *ctx, const tsr_corpus *corpus, const float *val
                         int64_t N, const int64_t *utt, const int64_t *starts, const int64_t *ends, int64_t W,
                         float *out);
 
+/* ---- edge front-end (edge_signal_proc.py) -------------------------- */
+/* get_edge_features, default branch (get_train_data.py:2547-2557): _edge_map_no_threshold
+ * (edge_signal_proc.py:1697-1836) -> _edge_map_threshold_segments (:1537-1675: per block of
+ * block_length frames and per orientation the quantile-th sorted positive value, floored at
+ * abst_threshold[e], then the binary map spread +-spread_length steps along the orientation inside
+ * the block; the trailing partial block is processed on the last block_length frames and only its own
+ * frames are kept) -> reorg_part_for_fast_filtering.  S_cat f64 [sum T_n, H] is the spectrogram stream
+ * TIME-major (the reference's S before the `.T` of get_edge_features(S.T, ...)); the result is a new
+ * resident corpus with D = 8 H, byte h*8 + e of a frame = orientation e at frequency h, ready for
+ * tsr_corpus_part_features / tsr_corpus_score.  abst_threshold f64 [8]; 0 <= quantile < 1. */
+int tsr_edge_corpus_create(tsr_ctx *ctx, const double *S_cat, const int64_t *frame_offsets, int64_t N,
+                           int64_t H, int block_length, int spread_length, double quantile,
+                           const double *abst_threshold, tsr_corpus **out);
+
 /* ---- multi-GPU: utterances shard across ranks, the bank is broadcast once ----- */
 /* One process per GPU.  Rank 0 calls tsr_dist_unique_id and hands the 128 bytes
  * to the other ranks over any host channel; every rank then calls

@@ -402,3 +402,94 @@ def get_max_detection_in_syllable_windows(detection_array, example_start_end_tim
     if return_argsort_idx:
         return np.sort(max_detect_vals), np.argsort(max_detect_vals), np.array(utterance_ids)
     return np.sort(max_detect_vals)
+
+
+# ---- edge front-end, restated from text: edge_signal_proc.py is a Python-2 module
+# without a native part ("parity unpinned": HIP kernel vs this NumPy restatement only).
+EDGE_ORIENTATIONS = np.array([[0, 1], [0, -1], [1, 0], [-1, 0], [1, 1], [-1, -1], [-1, 1], [1, -1]])
+ABST_THRESHOLD = np.array([0.025, 0.025, 0.015, 0.015, 0.02, 0.02, 0.02, 0.02])
+
+
+def edge_map_no_threshold(S):
+    """edge_signal_proc.py:1697-1836 for S [H, T] (frequency x time) -> E f64 [8H, T]: per orientation the
+    first difference along it, kept where it is a local maximum (>= both neighbours along the same
+    orientation) and of the orientation's sign."""
+    S = np.asarray(S, np.float64)
+    H, T = S.shape
+    E = np.zeros((8 * H, T))
+
+    def keep(d, lo, hi, sign):            # d, lo, hi: equally shaped difference arrays
+        d = sign * d
+        return d * ((d >= sign * lo) * (d >= sign * hi) * (d >= 0))
+
+    if T >= 4:
+        d = S[:, 1:] - S[:, :-1]          # along time
+        for e, sg in ((0, 1.0), (1, -1.0)):
+            E[e * H:(e + 1) * H, 1:-2] = keep(d[:, 1:-1], d[:, :-2], d[:, 2:], sg)
+    if H >= 4:
+        d = S[1:, :] - S[:-1, :]          # along frequency
+        for e, sg in ((2, 1.0), (3, -1.0)):
+            E[e * H + 1:(e + 1) * H - 2, :] = keep(d[1:-1, :], d[:-2, :], d[2:, :], sg)
+    if H >= 4 and T >= 4:
+        d = S[1:, 1:] - S[:-1, :-1]       # diagonal
+        for e, sg in ((4, 1.0), (5, -1.0)):
+            E[e * H + 1:(e + 1) * H - 2, 1:-2] = keep(d[1:-1, 1:-1], d[:-2, :-2], d[2:, 2:], sg)
+        d = S[:-1, 1:] - S[1:, :-1]       # anti-diagonal
+        for e, sg in ((6, 1.0), (7, -1.0)):
+            E[e * H + 1:(e + 1) * H - 2, 1:-2] = keep(d[1:-1, 1:-1], d[2:, :-2], d[:-2, 2:], sg)
+    return E
+
+
+def _threshold_edge_block(B, quantile_level, abst):
+    """edge_signal_proc.py:1257-1307 (convert_to_binary=True), in place on the view B."""
+    pos = B > 0
+    vals = np.sort(B[pos].ravel())
+    if vals.shape[0] <= 0:
+        B[:] = 0
+        return
+    tau = vals[int(quantile_level * vals.shape[0])]
+    B[:] = (pos & (B >= max(tau, abst))).astype(np.float64)
+
+
+def _spread_edges(B, direction, spread_length):
+    """edge_signal_proc.py:1406-1418: max over shifts k*direction, k in [-s, s], zeros outside."""
+    F, T = B.shape
+    s = spread_length
+    Z = np.zeros((F + 2 * s, T + 2 * s))
+    Z[s:s + F, s:s + T] = B
+    out = np.zeros(B.shape)
+    for k in range(-s, s + 1):
+        out = np.maximum(out, Z[s + k * direction[0]:s + F + k * direction[0],
+                               s + k * direction[1]:s + T + k * direction[1]])
+    return out
+
+
+def edge_map_threshold_segments(E, block_length, spread_length, threshold=.7, abst_threshold=ABST_THRESHOLD):
+    """edge_signal_proc.py:1537-1675 (unidirectional spread, binary output), in place on E [8H, T]: the
+    trailing partial block is thresholded and spread on a copy of the LAST block_length columns and only its
+    own columns are written back; then every full block in turn."""
+    H8, T = E.shape
+    H = H8 // 8
+    num_full, last = T // block_length, T % block_length
+
+    def process(Bk):
+        for e in range(8):
+            sub = Bk[e * H:(e + 1) * H]
+            _threshold_edge_block(sub, threshold, abst_threshold[e])
+            if spread_length > 0:
+                sub[:] = _spread_edges(sub, EDGE_ORIENTATIONS[e], spread_length)
+
+    if last > 0:
+        last_E = E[:, -block_length:].copy()
+        process(last_E)
+        E[:, -last:] = last_E[:, -last:]
+    for b in range(num_full):
+        process(E[:, b * block_length:(b + 1) * block_length])
+    return E
+
+
+def get_edge_features(S, block_length=40, spread_length=1, threshold=.7, abst_threshold=ABST_THRESHOLD):
+    """get_train_data.py:2547-2557 (default branch): S [H, T] -> binary edge map uint8 [T, H, 8]."""
+    E = edge_map_no_threshold(S)
+    edge_map_threshold_segments(E, block_length, spread_length, threshold, abst_threshold)
+    return reorg_part_for_fast_filtering(E).astype(np.uint8)

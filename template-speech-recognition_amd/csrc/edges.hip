@@ -1,0 +1,215 @@
+// edges.hip -- the edge front-end, spectrogram -> binary edge map:
+//   _edge_map_no_threshold        edge_signal_proc.py:1697-1836
+//   _edge_map_threshold_segments  edge_signal_proc.py:1537-1675  (unidirectional spread, binary)
+//     threshold_edge_block        :1257-1307   quantile of the positive values, by sorting
+//     _spread_edges               :1406-1418   max over shifts along the edge's orientation
+//   reorg_part_for_fast_filtering get_train_data.py:41-51       -> [T, H, 8]
+// as get_edge_features chains them (get_train_data.py:2547-2557, default branch).
+//
+// One workgroup per (utterance, block of block_length frames).  For each of the 8 orientations it
+//   1. evaluates the stencil from the f64 spectrogram: the first difference along the orientation,
+//      kept where it is >= both neighbouring differences and of the orientation's sign;
+//   2. finds the reference's threshold -- element int(q n) of the sorted positive values -- by an
+//      8-pass radix select on the f64 bit patterns (positive doubles order like their bits), no sort;
+//   3. thresholds at max(tau, abst[e]) and ORs the binary block along the orientation
+//      (+-spread_length steps, zeros outside the BLOCK, like the reference's zero-padded Z);
+// and finally writes the block's frames in the resident corpus layout [frame][h*8 + e] as whole rows.
+// All comparisons are the reference's f64 comparisons on the same operands, so the map is identical.
+#include "tsr_internal.h"
+
+#include <vector>
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct EdgeArgs {
+    const double *S;           // [P][H] time-major spectrogram stream
+    const int64_t *utt_off;    // [N+1]
+    const int32_t *item;       // [n_items][4]: utterance, first column of the window, width, first kept column
+    int H, spread, Dp, max_w;
+    double q;
+    double abst[8];
+    uint8_t *out;              // resident corpus rows [P][Dp]
+};
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(v, off);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(kThreads) void edge_block_kernel(const EdgeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t esm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = a.H;
+    const int32_t *it = a.item + (size_t)blockIdx.x * 4;
+    const int u = it[0], c0 = it[1], W = it[2], keep0 = it[3];
+    const int64_t o = a.utt_off[u];
+    const int T = (int)(a.utt_off[u + 1] - o);
+    const int n_el = H * W;
+    double *vals = reinterpret_cast<double *>(esm);                          // [H][W]
+    uint8_t *bin = reinterpret_cast<uint8_t *>(vals + (size_t)H * a.max_w);  // [H][W]
+    uint8_t *tile = bin + (((size_t)H * a.max_w + 15) & ~(size_t)15);       // [W][Dp]
+    int *hist = reinterpret_cast<int *>(tile + (size_t)a.max_w * a.Dp);      // [256]
+    int *red = hist + 256;                                                   // [8]: scratch
+    unsigned long long *sel = reinterpret_cast<unsigned long long *>(red + 8);  // [2]: prefix, k
+
+    for (int i = tid * 16; i < W * a.Dp; i += kThreads * 16) *reinterpret_cast<uint4 *>(tile + i) = make_uint4(0, 0, 0, 0);
+    auto Sv = [&](int h, int t) { return a.S[(o + t) * H + h]; };
+
+    for (int e = 0; e < 8; ++e) {
+        const int pair = e >> 1;
+        const double sg = (e & 1) ? -1.0 : 1.0;
+        // ---- 1. stencil ------------------------------------------------------------------------
+        int npos = 0;
+        for (int idx = tid; idx < n_el; idx += kThreads) {
+            const int h = idx / W, c = idx - h * W, t = c0 + c;
+            double v = 0.0;
+            const bool tin = t >= 1 && t < T - 2, hin = h >= 1 && h < H - 2;
+            double d = 0.0, lo = 0.0, hi = 0.0;
+            bool ok = false;
+            if (pair == 0 && tin) {  // along time
+                d = Sv(h, t + 1) - Sv(h, t);
+                lo = Sv(h, t) - Sv(h, t - 1);
+                hi = Sv(h, t + 2) - Sv(h, t + 1);
+                ok = true;
+            } else if (pair == 1 && hin) {  // along frequency
+                d = Sv(h + 1, t) - Sv(h, t);
+                lo = Sv(h, t) - Sv(h - 1, t);
+                hi = Sv(h + 2, t) - Sv(h + 1, t);
+                ok = true;
+            } else if (pair == 2 && hin && tin) {  // diagonal
+                d = Sv(h + 1, t + 1) - Sv(h, t);
+                lo = Sv(h, t) - Sv(h - 1, t - 1);
+                hi = Sv(h + 2, t + 2) - Sv(h + 1, t + 1);
+                ok = true;
+            } else if (pair == 3 && hin && tin) {  // anti-diagonal
+                d = Sv(h, t + 1) - Sv(h + 1, t);
+                lo = Sv(h + 1, t) - Sv(h + 2, t - 1);
+                hi = Sv(h - 1, t + 2) - Sv(h, t + 1);
+                ok = true;
+            }
+            if (ok) {
+                d *= sg;
+                lo *= sg;
+                hi *= sg;
+                if (d >= lo && d >= hi && d >= 0.0) v = d;
+            }
+            vals[idx] = v;
+            npos += v > 0.0;
+        }
+        // ---- 2. n, k = int(q n), k-th smallest positive value ------------------------------------
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) npos += __shfl_xor(npos, off);
+        if (lane == 0) red[wave] = npos;
+        __syncthreads();
+        const int n = red[0] + red[1] + red[2] + red[3];
+        double thr = 0.0;
+        if (n > 0) {
+            if (tid == 0) {
+                sel[0] = 0ull;
+                sel[1] = (unsigned long long)(long long)(a.q * (double)n);
+            }
+            for (int pass = 7; pass >= 0; --pass) {
+                const int shift = 8 * pass;
+                hist[tid] = 0;
+                __syncthreads();
+                const unsigned long long prefix = sel[0];
+                for (int idx = tid; idx < n_el; idx += kThreads) {
+                    const double v = vals[idx];
+                    if (v > 0.0) {
+                        const unsigned long long key = (unsigned long long)__double_as_longlong(v);
+                        if (pass == 7 || (key >> (shift + 8)) == (prefix >> (shift + 8)))
+                            atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
+                    }
+                }
+                __syncthreads();
+                if (wave == 0) {  // bin whose cumulative count passes k
+                    const int kk = (int)sel[1];
+                    const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+                    const int incl = wave_incl_scan(h0 + h1 + h2 + h3, lane);
+                    const int excl = incl - (h0 + h1 + h2 + h3);
+                    if (kk >= excl && kk < incl) {
+                        int b = 0, cum = excl;
+                        if (kk >= cum + h0) {
+                            cum += h0;
+                            b = 1;
+                            if (kk >= cum + h1) {
+                                cum += h1;
+                                b = 2;
+                                if (kk >= cum + h2) {
+                                    cum += h2;
+                                    b = 3;
+                                }
+                            }
+                        }
+                        sel[0] = prefix | ((unsigned long long)(4 * lane + b) << shift);
+                        sel[1] = (unsigned long long)(kk - cum);
+                    }
+                }
+                __syncthreads();
+            }
+            const double tau = __longlong_as_double((long long)sel[0]);
+            thr = tau > a.abst[e] ? tau : a.abst[e];  // max(tau_quant, abst_threshold)
+        }
+        // ---- 3. threshold ------------------------------------------------------------------------
+        for (int idx = tid; idx < n_el; idx += kThreads) {
+            const double v = vals[idx];
+            bin[idx] = (n > 0 && v > 0.0 && v >= thr) ? 1 : 0;
+        }
+        __syncthreads();
+        // ---- 4. spread along the orientation inside the block, into the frame tile ----------------
+        const int d0 = pair == 0 ? 0 : (pair == 3 ? -1 : 1), d1 = pair == 1 ? 0 : 1;
+        for (int idx = tid; idx < n_el; idx += kThreads) {
+            const int h = idx / W, c = idx - h * W;
+            uint8_t r = bin[idx];
+            for (int k = 1; k <= a.spread; ++k) {
+                const int ha = h + k * d0, ca = c + k * d1, hb = h - k * d0, cb = c - k * d1;
+                if (ha >= 0 && ha < H && ca >= 0 && ca < W) r |= bin[ha * W + ca];
+                if (hb >= 0 && hb < H && cb >= 0 && cb < W) r |= bin[hb * W + cb];
+            }
+            tile[(size_t)c * a.Dp + h * 8 + e] = r;
+        }
+        __syncthreads();
+    }
+    // ---- the kept frames of the block, whole resident rows -------------------------------------------
+    const int row16 = a.Dp >> 4;
+    for (int i = tid; i < (W - keep0) * row16; i += kThreads) {
+        const int c = keep0 + i / row16, s16 = i - (c - keep0) * row16;
+        *reinterpret_cast<uint4 *>(a.out + (o + c0 + c) * (int64_t)a.Dp + s16 * 16) =
+            *reinterpret_cast<const uint4 *>(tile + (size_t)c * a.Dp + s16 * 16);
+    }
+}
+
+}  // namespace
+
+int tsr_launch_edge_blocks(tsr_ctx *ctx, const double *d_S, const int64_t *d_utt_off, const int32_t *d_items,
+                           int64_t n_items, int H, int block_length, int spread, double q, const double *abst,
+                           int Dp, uint8_t *d_out)
+{
+    if (n_items <= 0) return TSR_OK;
+    EdgeArgs a;
+    a.S = d_S;
+    a.utt_off = d_utt_off;
+    a.item = d_items;
+    a.H = H;
+    a.spread = spread;
+    a.Dp = Dp;
+    a.max_w = block_length;
+    a.q = q;
+    for (int e = 0; e < 8; ++e) a.abst[e] = abst[e];
+    a.out = d_out;
+    const size_t hw = (size_t)H * block_length;
+    const size_t lds = hw * 8 + ((hw + 15) & ~(size_t)15) + (size_t)block_length * Dp + 256 * 4 + 8 * 4 + 16 + 16;
+    if (lds > 160 * 1024) return TSR_ERR_UNSUPPORTED;
+    TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(edge_block_kernel, dim3((unsigned)n_items), dim3(kThreads), lds, ctx->stream, a);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}

@@ -721,6 +721,58 @@ TSR_API int tsr_window_peak_max(tsr_ctx *ctx, const tsr_corpus *cp, const float 
     return TSR_OK;
 }
 
+// ---- edge front-end ---------------------------------------------------
+// get_edge_features, default branch (get_train_data.py:2547-2557): spectrograms -> a resident binary
+// edge corpus (D = 8 H, layout [frame][h][edge type] = reorg_part_for_fast_filtering).
+TSR_API int tsr_edge_corpus_create(tsr_ctx *ctx, const double *S_cat, const int64_t *frame_offsets, int64_t N,
+                                   int64_t H, int block_length, int spread_length, double quantile,
+                                   const double *abst_threshold, tsr_corpus **out)
+{
+    TSR_REQUIRE(ctx && frame_offsets && out && abst_threshold, "tsr_edge_corpus_create: null pointer");
+    *out = nullptr;
+    TSR_REQUIRE(N >= 0 && H >= 1 && H <= 4096 && block_length >= 1 && spread_length >= 0,
+                "tsr_edge_corpus_create: bad geometry (H=%lld, block_length=%d, spread_length=%d)", (long long)H, block_length, spread_length);
+    TSR_REQUIRE(quantile >= 0.0 && quantile < 1.0, "tsr_edge_corpus_create: quantile %g outside [0, 1) (the reference indexes past its sorted values at 1)", quantile);
+    TSR_REQUIRE(frame_offsets[0] == 0, "tsr_edge_corpus_create: frame_offsets[0] must be 0");
+    std::vector<int32_t> items;
+    for (int64_t n = 0; n < N; ++n) {
+        const int64_t T = frame_offsets[n + 1] - frame_offsets[n];
+        TSR_REQUIRE(T >= 0 && T < ((int64_t)1 << 30), "tsr_edge_corpus_create: bad utterance length");
+        const int64_t full = T / block_length, last = T % block_length;
+        if (last > 0) {  // the trailing partial block: thresholded on the last block_length columns, only its own kept
+            const int64_t c0 = std::max<int64_t>(0, T - block_length), w = std::min<int64_t>(block_length, T);
+            items.insert(items.end(), {(int32_t)n, (int32_t)c0, (int32_t)w, (int32_t)(w - last)});
+        }
+        for (int64_t b = 0; b < full; ++b) items.insert(items.end(), {(int32_t)n, (int32_t)(b * block_length), block_length, 0});
+    }
+    const int64_t P = frame_offsets[N];
+    TSR_REQUIRE(P == 0 || S_cat, "tsr_edge_corpus_create: null spectrogram");
+    TSR_HIP(hipSetDevice(ctx->device));
+    tsr_corpus *cp = nullptr;
+    TSR_TRY(tsr_corpus_create_empty(ctx, frame_offsets, N, 8 * H, &cp));
+    void *dS = nullptr, *dO = nullptr, *dI = nullptr;
+    int s = tsr_scratch(ctx, SLOT_RAW, (size_t)std::max<int64_t>(P * H, 1) * 8, &dS);
+    if (s == TSR_OK) s = tsr_scratch(ctx, SLOT_AUX, (size_t)(N + 1) * 8, &dO);
+    if (s == TSR_OK) s = tsr_scratch(ctx, SLOT_W, std::max<size_t>(items.size(), 4) * 4, &dI);
+    if (s == TSR_OK && P > 0 &&
+        (hipMemcpyAsync(dS, S_cat, (size_t)(P * H) * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+         hipMemcpyAsync(dO, frame_offsets, (size_t)(N + 1) * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+         hipMemcpyAsync(dI, items.data(), items.size() * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess))
+        s = TSR_ERR_HIP;
+    if (s == TSR_OK && P > 0)
+        s = tsr_launch_edge_blocks(ctx, (const double *)dS, (const int64_t *)dO, (const int32_t *)dI, (int64_t)(items.size() / 4),
+                                   (int)H, block_length, spread_length, quantile, abst_threshold, cp->Dp, cp->d_feats);
+    if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
+    if (s != TSR_OK) {
+        if (s == TSR_ERR_HIP) tsr_set_error("tsr_edge_corpus_create: device copy/launch failed");
+        if (s == TSR_ERR_UNSUPPORTED) tsr_set_error("tsr_edge_corpus_create: H=%lld x block_length=%d does not fit the LDS", (long long)H, block_length);
+        tsr_corpus_destroy(cp);
+        return s;
+    }
+    *out = cp;
+    return TSR_OK;
+}
+
 // ---- single-utterance drop-ins ----------------------------------------------------
 TSR_API int tsr_detect_u8(tsr_ctx *ctx, const uint8_t *F, int64_t T, int64_t D, const float *LF,
                           int64_t L, float *out)

@@ -4,6 +4,7 @@ the native kernels, re-hosted on the GPU path:
     reorg_part_for_fast_filtering / reorg_parts_for_fast_filtering   :41-57
     collapse_to_grid                                                  :72-81
     get_waliji_feature_map (from the edge map on)                     :182-191
+    get_edge_features (default branch)                                :2489-2557
     get_classify_windows / _compute_classification_E                  :710-773
     get_isolated_classify_windows / _compute_isolated_classification_E :781-925
     _compute_detection_E (scoring + template ids)                     :927-1012
@@ -279,3 +280,31 @@ def get_classify_scores_E(utterances, flts_list, linear_filters_cs, bgd=None, is
                               classify_array, classify_template_ids, classify_template_lengths, classify_locs)
         k += m
     return classify_array, classify_locs, classify_template_lengths, classify_template_ids
+
+
+# ---- edge front-end (:2489-2557) ----------------------------------------------------------------
+def get_edge_features(S, parameters, verbose=False):
+    """Spectrogram S [H, T] (features x time, as the reference passes `S.T`) -> thresholded, spread edge
+    map [T, H, 8] (float64 zeros and ones like the reference's; callers cast to uint8).  Only the
+    default branch of the reference (`_edge_map_no_threshold` + `_edge_map_threshold_segments` +
+    `reorg_part_for_fast_filtering`, :2547-2557) -- the magnitude / auxiliary-data variants are not
+    covered.  `parameters` is duck-typed like get_train_data.EdgemapParameters (block_length,
+    spread_length, threshold, optionally abst_threshold)."""
+    for flag in ("auxiliary_data", "magnitude_features", "magnitude_and_edge_features", "magnitude_thresholded_edges"):
+        if getattr(parameters, flag, False):
+            raise NotImplementedError("get_edge_features: only the plain edge-map branch runs on the GPU (%s set)" % flag)
+    return get_edge_corpus([np.asarray(S, np.float64).T], parameters).download_feats().reshape(
+        S.shape[1], S.shape[0], 8).astype(np.float64)
+
+
+def get_edge_corpus(spectrograms, parameters, ctx=None):
+    """The same for a list of time-major spectrograms [T_n, H], all utterances in one launch; the result
+    stays on the device as a corpus (feed it to Corpus.part_features / Corpus.score)."""
+    specs = [np.ascontiguousarray(S, dtype=np.float64) for S in spectrograms]
+    offs = np.concatenate(([0], np.cumsum([S.shape[0] for S in specs]))).astype(np.int64)
+    kw = {}
+    if getattr(parameters, "abst_threshold", None) is not None:
+        kw["abst_threshold"] = parameters.abst_threshold
+    return api.Corpus.from_spectrograms(np.concatenate(specs), offs, block_length=parameters.block_length,
+                                        spread_length=parameters.spread_length, threshold=parameters.threshold,
+                                        ctx=ctx, **kw)

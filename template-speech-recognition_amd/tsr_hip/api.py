@@ -205,6 +205,24 @@ class Corpus:
             pass
 
     @classmethod
+    def from_spectrograms(cls, S_cat, frame_offsets, block_length=40, spread_length=1, threshold=.7,
+                          abst_threshold=(0.025, 0.025, 0.015, 0.015, 0.02, 0.02, 0.02, 0.02), ctx=None):
+        """Edge front-end on the device (get_edge_features, get_train_data.py:2547-2557): spectrogram
+        stream f64 [sum T, H] (time-major) -> resident binary edge corpus with D = 8 H."""
+        ctx = ctx or default_ctx()
+        S = np.ascontiguousarray(S_cat, dtype=np.float64)
+        offs = np.ascontiguousarray(frame_offsets, dtype=np.int64)
+        if S.ndim != 2 or S.shape[0] != int(offs[-1]):
+            raise ValueError("S_cat must be [frame_offsets[-1], H]")
+        ab = np.ascontiguousarray(abst_threshold, dtype=np.float64)
+        if ab.shape != (8,):
+            raise ValueError("abst_threshold needs 8 values")
+        h = C.c_void_p()
+        check(lib().tsr_edge_corpus_create(ctx._h, ptr(S), ptr(offs), len(offs) - 1, S.shape[1], int(block_length),
+                                           int(spread_length), float(threshold), ptr(ab), C.byref(h)))
+        return cls._adopt(h, ctx)
+
+    @classmethod
     def _adopt(cls, handle, ctx):
         """Wrap a tsr_corpus* produced on the device (no upload)."""
         self = cls.__new__(cls)

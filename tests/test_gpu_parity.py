@@ -617,3 +617,39 @@ def test_config4_share_fullsize_properties(mods, oracle):
     cf = np.array([np.float32(cc) for _, cc in c["bank"]])
     tail = se.reshape(1250, 200)[:, 200 - min(L) + 1:]    # frames that are tail for EVERY template
     assert np.all(tail == cf.max())
+
+
+# ---- edge front-end: HIP kernel vs the NumPy restatement of edge_signal_proc.py ------
+@pytest.mark.parametrize("case", [
+    dict(H=45, Ts=[200, 87, 40, 39, 41, 3, 1, 0, 120], BL=40, s=1, q=.7),      # the reference's defaults
+    dict(H=12, Ts=[57, 20, 19, 4], BL=20, s=3, q=.5),                           # wide spread, block == utterance
+    dict(H=4, Ts=[33, 5], BL=7, s=0, q=.9),                                     # no spread, minimal height
+    dict(H=3, Ts=[10], BL=4, s=1, q=.0),                                        # too low for the vertical stencils
+    dict(H=30, Ts=[64], BL=64, s=2, q=.7, quantised=True),                      # plateaus: ties in the quantile
+])
+def test_edge_front_end(mods, oracle, case):
+    tsr_hip = mods[3]
+    rng = np.random.default_rng(case["H"] * 1000 + case["BL"])
+    H, Ts = case["H"], case["Ts"]
+    specs = []
+    for T in Ts:
+        S = rng.normal(size=(T, H)).cumsum(0) + 0.3 * rng.normal(size=(T, H))
+        if case.get("quantised"):
+            S = np.round(S * 2) / 2
+        specs.append(S)
+    offs = np.concatenate(([0], np.cumsum(Ts))).astype(np.int64)
+    corpus = tsr_hip.Corpus.from_spectrograms(np.concatenate(specs) if specs else np.zeros((0, H)), offs,
+                                              block_length=case["BL"], spread_length=case["s"], threshold=case["q"])
+    assert corpus.D == 8 * H and corpus.offsets.tolist() == offs.tolist()
+    got = corpus.download_feats()
+    for n, S in enumerate(specs):
+        want = oracle.get_edge_features(S.T, block_length=case["BL"], spread_length=case["s"], threshold=case["q"])
+        assert np.array_equal(got[offs[n]:offs[n + 1]].reshape(len(S), H, 8), want), (case, n)
+    if H == 45:   # and on through the parts coder and the bank, all on the device
+        from tsr_hip import synth
+        lp, lip = synth.parts(rng, 20)
+        pc = corpus.part_features(tsr_hip.Parts(lp, lip), 12, spread=(1, 1))
+        want0 = _oracle_part_chain(oracle, [got[offs[0]:offs[1]].reshape(Ts[0], H, 8)], lp, lip, 12, (1, 1), (1, 1), False, 20)[0]
+        assert np.array_equal(pc.download_feats()[:want0.shape[0]], want0.reshape(want0.shape[0], -1))
+    with pytest.raises(ValueError):
+        tsr_hip.Corpus.from_spectrograms(np.zeros((4, 5)), [0, 4], threshold=1.0)
