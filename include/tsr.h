@@ -51,11 +51,20 @@ enum {
  *   TSR_FAST : MFMA path.  The bank is held as int8 limbs of a fixed-point encoding
  *              (per-template scale) and accumulated exactly in integers, so results
  *              are independent of summation order and bit-reproducible; the only
- *              error is the weight quantisation.  Two limbs (16-bit weights):
- *              <= 2^-16 * max|W_m| per tap -- the size of the rounding noise of the
- *              reference's own f32 sum, ~1e-6 relative on a window score.
+ *              error is the weight quantisation.  At least two limbs (16-bit weights):
+ *              |error| <= 2^-16 * max|W_m| per SET tap of the window in the worst case,
+ *              i.e. <= 2^-16 * (max|W_m| / mean|W|) relative to the sum of the magnitudes
+ *              of the added terms (the norm in which a floating-point sum is accurate at
+ *              all); the errors are unbiased, so the observed figure grows with the
+ *              square root of the tap count -- about 5e-3 absolute on BASELINE config 2
+ *              (11 520 taps, scores of order 10^3: 3e-6 relative), the size of the rounding
+ *              noise of the reference's own sequential f32 sum.  A window whose score is of
+ *              order one next to thousands of cancelling taps is NOT within 1e-4 of its own
+ *              value in this mode -- nor is the reference's f32 result within that of the
+ *              exact sum; ask for TSR_W24 or TSR_EXACT there.  Filters of at most 4096 taps
+ *              (Lmax * D) always get the third limb.
  *   TSR_FAST | TSR_W24: three limbs (23-bit weights, power-of-two scale),
- *              <= 2^-22 * max|W_m| per tap, at 1.5x the matrix-core work. */
+ *              <= 2^-22 * max|W_m| per set tap, at 1.5x the matrix-core work. */
 enum { TSR_EXACT = 0, TSR_FAST = 1, TSR_W24 = 2 };
 
 typedef struct tsr_ctx tsr_ctx;       /* device + stream + scratch                 */

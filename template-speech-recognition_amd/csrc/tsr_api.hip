@@ -409,6 +409,10 @@ static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp,
     TSR_REQUIRE(!(flags & TSR_W24) || (flags & TSR_FAST), "tsr_corpus_score: TSR_W24 modifies TSR_FAST");
     if (cp->P == 0) return TSR_OK;
     TSR_HIP(hipSetDevice(ctx->device));
+    // Short filters (few thousand taps) produce scores of order one, against which the 16-bit
+    // quantisation noise is no longer small; their launch is latency-bound anyway, so TSR_FAST
+    // takes the third limb there at no measurable cost (include/tsr.h, "at least 16-bit weights").
+    if ((flags & TSR_FAST) && (int64_t)bank->Lmax * bank->D <= TSR_FAST_W24_BELOW_TAPS) flags |= TSR_W24;
     if (flags & TSR_FAST) {
         const int NL = (flags & TSR_W24) ? 3 : 2;
         if (!bank->fast[NL - 2]) {

@@ -653,3 +653,24 @@ def test_edge_front_end(mods, oracle, case):
         assert np.array_equal(pc.download_feats()[:want0.shape[0]], want0.reshape(want0.shape[0], -1))
     with pytest.raises(ValueError):
         tsr_hip.Corpus.from_spectrograms(np.zeros((4, 5)), [0, 4], threshold=1.0)
+
+
+def test_fast_error_bound_and_short_filter_promotion(mods, oracle):
+    """include/tsr.h states TSR_FAST's error against the sum of magnitudes of the window's set taps; filters
+    of at most 4096 taps get the third limb automatically (their scores are of order one)."""
+    tsr_hip = mods[3]
+    from tsr_hip import synth
+    c = synth.corpus(31, N=3, T=[150, 64, 90], F=30, E=8, M=6, L=[20, 31, 44, 9, 60, 17])   # up to 14 400 taps: two limbs
+    bank = tsr_hip.Bank(c["bank"])
+    exact = bank.score_all(c["feats"], c["offsets"], flags=tsr_hip.TSR_EXACT)
+    scale = tsr_hip.Bank([(np.abs(W), 0.0) for W, _ in c["bank"]]).score_all(c["feats"], c["offsets"])
+    for flags, bound in ((tsr_hip.TSR_FAST, 1e-4), (tsr_hip.TSR_FAST | tsr_hip.TSR_W24, 2e-6)):
+        got = bank.score_all(c["feats"], c["offsets"], flags=flags)
+        assert float(np.max(np.abs(got - exact) / np.maximum(scale, 1.0))) <= bound
+    c = synth.corpus(32, N=2, T=[120, 75], F=3, E=8, M=4, L=[36, 51, 8, 64])               # <= 1536 taps: promoted
+    bank = tsr_hip.Bank(c["bank"])
+    a = bank.score_all(c["feats"], c["offsets"], flags=tsr_hip.TSR_FAST)
+    b = bank.score_all(c["feats"], c["offsets"], flags=tsr_hip.TSR_FAST | tsr_hip.TSR_W24)
+    assert np.array_equal(a, b)
+    exact = bank.score_all(c["feats"], c["offsets"], flags=tsr_hip.TSR_EXACT)
+    assert rel_err(a, exact) <= TOL
