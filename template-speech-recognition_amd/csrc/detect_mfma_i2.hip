@@ -1,0 +1,9 @@
+// Instantiations of the MFMA bank kernel for NKB = 9..12 (see detect_mfma_kernel.inc).
+#include "detect_mfma_kernel.inc"
+
+namespace tsr_fast {
+template int launch<9>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
+template int launch<10>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
+template int launch<11>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
+template int launch<12>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
+}  // namespace tsr_fast

@@ -6,7 +6,7 @@ PKG=template-speech-recognition_amd
 if [ "$1" = build ]; then
   for n in $2; do
     /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -fvisibility=hidden -Wno-unused-parameter -DTSR_ABL=$n \
-      -o $PKG/lib/libtsr_abl$n.so $PKG/csrc/tsr_api.hip $PKG/csrc/detect_exact.hip $PKG/csrc/detect_mfma.hip $PKG/csrc/parts.hip -ldl &
+      -o $PKG/lib/libtsr_abl$n.so $PKG/csrc/*.hip -ldl &
   done; wait; ls $PKG/lib
 else
   for n in $2; do
