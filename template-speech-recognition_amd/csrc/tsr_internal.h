@@ -71,7 +71,7 @@ int tsr_corpus_create_empty(tsr_ctx *ctx, const int64_t *frame_offsets, int64_t 
 // TSR_FAST uses three limbs when the longest filter has at most this many taps (Lmax * D).
 #define TSR_FAST_W24_BELOW_TAPS 4096
 
-// Fast (MFMA) path: see detect_mfma.hip for the limb layout.
+// Fast (MFMA) path: see detect_mfma_kernel.inc for the limb layout.
 struct tsr_bank {
     tsr_ctx *ctx = nullptr;
     int device = 0;
