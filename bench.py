@@ -211,9 +211,12 @@ def main():
     for _ in range(args.steps):
         dev_corpus.score(bank, flags)
     kernel_ms = ctx.timer_stop()          # hipEvents on the launch stream
-    barrier()
-    wall = time.perf_counter() - t0
+    ctx.sync()
+    wall = time.perf_counter() - t0       # this rank: common start (barrier above) -> its own last step done
+    barrier()                             # closing bracket: every rank has finished
     if dist is not None:
+        # MAX over ranks of the per-rank intervals.  The closing barrier itself (a TCP round of the host
+        # control plane, hundreds of microseconds against K x 37 us of work) is not GPU time of any rank.
         wall, kernel_ms = tdist.max_over_ranks(dist, wall, kernel_ms)
 
     # ---- parity spot check on what was just computed (rank 0, oracle as checker) -----
