@@ -115,3 +115,32 @@ def test_synth_corpus_shapes():
     assert c["feats"].shape == (31, 4, 2) and c["offsets"].tolist() == [0, 10, 22, 31]
     assert [w.shape[0] for w, _ in c["bank"]] == [3, 5, 4]
     assert set(np.unique(c["feats"])) <= {0, 1}
+
+
+def test_isolated_virtual_windows_describe_the_reference_windows(oracle):
+    """Host logic of the isolated classification: the (first frame, real range, row count, searched
+    positions) description handed to tsr_corpus_classify_isolated must reproduce, row for row, the
+    background-padded windows get_isolated_classify_windows builds (get_train_data.py:781-835)."""
+    import template_speech_rec.get_train_data as gtrd
+    from tsr_hip import synth
+    rng = np.random.default_rng(8)
+    for trial in range(30):
+        F, E = int(rng.integers(1, 6)), int(rng.choice([1, 8]))
+        q = synth.background(rng, (F, E)).astype(np.float32)
+        Ls = [int(x) for x in rng.integers(1, 40, size=int(rng.integers(1, 5)))]
+        bank = synth.bank(rng, q, Ls)
+        T = int(rng.integers(8, 140))
+        Em = synth.features(rng, T, q)
+        cuts = np.sort(rng.choice(np.arange(2, T - 1), size=min(int(rng.integers(1, 8)), T - 3), replace=False))
+        flts = np.concatenate(([0], cuts, [T])).astype(np.int64)
+        wins, ws, we, pad0 = oracle.get_isolated_classify_windows(Em, None, flts.copy(), q, bank)
+        frame0 = int(rng.integers(0, 1000))
+        first, lo, hi, rows, n_valid, ws2, pad2, _ = gtrd._isolated_virtual_windows(T, flts, max(Ls), frame0=frame0)
+        assert np.array_equal(ws2, ws.astype(np.int64)) and pad2 == int(pad0)
+        assert np.array_equal(n_valid, we.astype(np.int64) - ws.astype(np.int64))
+        for w, win in enumerate(wins):
+            assert rows[w] == len(win)
+            for r in range(len(win)):
+                f = first[w] + r
+                want = Em[f - frame0].astype(np.float32) if lo[w] <= f < hi[w] else q
+                assert np.array_equal(win[r], want), (trial, w, r)
