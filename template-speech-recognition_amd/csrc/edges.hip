@@ -187,6 +187,164 @@ __global__ __launch_bounds__(kThreads) void edge_block_kernel(const EdgeArgs a)
     }
 }
 
+// The same block, one WAVE per orientation (8 waves): the block's values of an orientation stay in the
+// lanes' registers (EPL per lane), the radix select keeps its histogram in a per-wave LDS strip and its
+// state in wave-uniform registers, so no workgroup barrier is needed until the frame tile is complete.
+// Used when H * block_length <= 64 * EPL; edge_block_kernel above serves larger blocks.
+template <int EPL>
+__global__ __launch_bounds__(512) void edge_block_wave_kernel(const EdgeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t esm[];
+    const int tid = threadIdx.x, lane = tid & 63, e = tid >> 6;  // wave = orientation
+    const int H = a.H;
+    const int32_t *it = a.item + (size_t)blockIdx.x * 4;
+    const int u = it[0], c0 = it[1], W = it[2], keep0 = it[3];
+    const int64_t o = a.utt_off[u];
+    const int T = (int)(a.utt_off[u + 1] - o);
+    const int n_el = H * W;
+    const size_t hw = ((size_t)H * a.max_w + 15) & ~(size_t)15;
+    uint8_t *tile = esm;                                            // [W][Dp]
+    uint8_t *bin = tile + (size_t)a.max_w * a.Dp + (size_t)e * hw;  // this wave's [H][W]
+    int *hist = reinterpret_cast<int *>(tile + (size_t)a.max_w * a.Dp + 8 * hw) + e * 256;
+
+    for (int i = tid * 16; i < W * a.Dp; i += 512 * 16) *reinterpret_cast<uint4 *>(tile + i) = make_uint4(0, 0, 0, 0);
+    auto Sv = [&](int h, int t) { return a.S[(o + t) * H + h]; };
+    const int pair = e >> 1;
+    const double sg = (e & 1) ? -1.0 : 1.0;
+    // ---- 1. stencil into registers ------------------------------------------------------------------
+    double v[EPL];
+    int npos = 0;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int idx = lane + 64 * i;
+        double x = 0.0;
+        if (idx < n_el) {
+            const int h = idx / W, c = idx - h * W, t = c0 + c;
+            const bool tin = t >= 1 && t < T - 2, hin = h >= 1 && h < H - 2;
+            double d = 0.0, lo = 0.0, hi = 0.0;
+            bool ok = false;
+            if (pair == 0 && tin) {
+                d = Sv(h, t + 1) - Sv(h, t);
+                lo = Sv(h, t) - Sv(h, t - 1);
+                hi = Sv(h, t + 2) - Sv(h, t + 1);
+                ok = true;
+            } else if (pair == 1 && hin) {
+                d = Sv(h + 1, t) - Sv(h, t);
+                lo = Sv(h, t) - Sv(h - 1, t);
+                hi = Sv(h + 2, t) - Sv(h + 1, t);
+                ok = true;
+            } else if (pair == 2 && hin && tin) {
+                d = Sv(h + 1, t + 1) - Sv(h, t);
+                lo = Sv(h, t) - Sv(h - 1, t - 1);
+                hi = Sv(h + 2, t + 2) - Sv(h + 1, t + 1);
+                ok = true;
+            } else if (pair == 3 && hin && tin) {
+                d = Sv(h, t + 1) - Sv(h + 1, t);
+                lo = Sv(h + 1, t) - Sv(h + 2, t - 1);
+                hi = Sv(h - 1, t + 2) - Sv(h, t + 1);
+                ok = true;
+            }
+            if (ok) {
+                d *= sg;
+                lo *= sg;
+                hi *= sg;
+                if (d >= lo && d >= hi && d >= 0.0) x = d;
+            }
+        }
+        v[i] = x;
+        npos += x > 0.0;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) npos += __shfl_xor(npos, off);
+    const int n = npos;
+    // ---- 2. k-th smallest positive value: 8-pass radix select, state in wave-uniform registers ---------
+    double thr = 0.0;
+    if (n > 0) {
+        unsigned long long prefix = 0;
+        int kk = (int)(a.q * (double)n);
+        for (int pass = 7; pass >= 0; --pass) {
+            const int shift = 8 * pass;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) hist[4 * lane + b] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < EPL; ++i)
+                if (v[i] > 0.0) {
+                    const unsigned long long key = (unsigned long long)__double_as_longlong(v[i]);
+                    if (pass == 7 || (key >> (shift + 8)) == (prefix >> (shift + 8)))
+                        atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
+                }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const int incl = wave_incl_scan(h0 + h1 + h2 + h3, lane);
+            const int excl = incl - (h0 + h1 + h2 + h3);
+            const bool mine = kk >= excl && kk < incl;
+            int b = 0, cum = excl;
+            if (kk >= cum + h0) {
+                cum += h0;
+                b = 1;
+                if (kk >= cum + h1) {
+                    cum += h1;
+                    b = 2;
+                    if (kk >= cum + h2) {
+                        cum += h2;
+                        b = 3;
+                    }
+                }
+            }
+            const int src = __builtin_ctzll(__builtin_amdgcn_ballot_w64(mine));  // exactly one lane holds k
+            const int digit = __shfl(4 * lane + b, src);
+            kk = __shfl(kk - cum, src);
+            prefix |= (unsigned long long)digit << shift;
+            __builtin_amdgcn_wave_barrier();  // everyone has read the histogram before it is cleared again
+        }
+        const double tau = __longlong_as_double((long long)prefix);
+        thr = tau > a.abst[e] ? tau : a.abst[e];
+    }
+    // ---- 3. threshold -> this wave's binary block in LDS -----------------------------------------------
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < n_el) bin[idx] = (n > 0 && v[i] > 0.0 && v[i] >= thr) ? 1 : 0;
+    }
+    __syncthreads();  // (also: the tile is zeroed)
+    // ---- 4. spread along the orientation inside the block, into the frame tile -------------------------
+    const int d0 = pair == 0 ? 0 : (pair == 3 ? -1 : 1), d1 = pair == 1 ? 0 : 1;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < n_el) {
+            const int h = idx / W, c = idx - h * W;
+            uint8_t r = bin[idx];
+            for (int k = 1; k <= a.spread; ++k) {
+                const int ha = h + k * d0, ca = c + k * d1, hb = h - k * d0, cb = c - k * d1;
+                if (ha >= 0 && ha < H && ca >= 0 && ca < W) r |= bin[ha * W + ca];
+                if (hb >= 0 && hb < H && cb >= 0 && cb < W) r |= bin[hb * W + cb];
+            }
+            tile[(size_t)c * a.Dp + h * 8 + e] = r;
+        }
+    }
+    __syncthreads();
+    const int row16 = a.Dp >> 4;
+    for (int i = tid; i < (W - keep0) * row16; i += 512) {
+        const int c = keep0 + i / row16, s16 = i - (c - keep0) * row16;
+        *reinterpret_cast<uint4 *>(a.out + (o + c0 + c) * (int64_t)a.Dp + s16 * 16) =
+            *reinterpret_cast<const uint4 *>(tile + (size_t)c * a.Dp + s16 * 16);
+    }
+}
+
+template <int EPL>
+int launch_edge_wave(tsr_ctx *ctx, const EdgeArgs &a, int64_t n_items, size_t lds)
+{
+    TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_block_wave_kernel<EPL>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(edge_block_wave_kernel<EPL>, dim3((unsigned)n_items), dim3(512), lds, ctx->stream, a);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+
 }  // namespace
 
 int tsr_launch_edge_blocks(tsr_ctx *ctx, const double *d_S, const int64_t *d_utt_off, const int32_t *d_items,
@@ -206,6 +364,15 @@ int tsr_launch_edge_blocks(tsr_ctx *ctx, const double *d_S, const int64_t *d_utt
     for (int e = 0; e < 8; ++e) a.abst[e] = abst[e];
     a.out = d_out;
     const size_t hw = (size_t)H * block_length;
+    {  // one wave per orientation while the block fits the lanes' registers
+        const size_t hw16 = (hw + 15) & ~(size_t)15;
+        const size_t lds_w = (size_t)block_length * Dp + 8 * hw16 + 8 * 256 * 4;
+        if (hw <= 64 * 32 && lds_w <= 64 * 1024) {
+            if (hw <= 64 * 8) return launch_edge_wave<8>(ctx, a, n_items, lds_w);
+            if (hw <= 64 * 16) return launch_edge_wave<16>(ctx, a, n_items, lds_w);
+            return launch_edge_wave<32>(ctx, a, n_items, lds_w);
+        }
+    }
     const size_t lds = hw * 8 + ((hw + 15) & ~(size_t)15) + (size_t)block_length * Dp + 256 * 4 + 8 * 4 + 16 + 16;
     if (lds > 160 * 1024) return TSR_ERR_UNSUPPORTED;
     TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -626,6 +626,7 @@ def test_config4_share_fullsize_properties(mods, oracle):
     dict(H=4, Ts=[33, 5], BL=7, s=0, q=.9),                                     # no spread, minimal height
     dict(H=3, Ts=[10], BL=4, s=1, q=.0),                                        # too low for the vertical stencils
     dict(H=30, Ts=[64], BL=64, s=2, q=.7, quantised=True),                      # plateaus: ties in the quantile
+    dict(H=45, Ts=[130, 49], BL=50, s=1, q=.7),                                 # block too large for the per-wave kernel
 ])
 def test_edge_front_end(mods, oracle, case):
     tsr_hip = mods[3]
