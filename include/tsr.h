@@ -131,6 +131,9 @@ int tsr_corpus_create(tsr_ctx *ctx, const uint8_t *feats, const int64_t *frame_o
                       int64_t D, tsr_corpus **out);
 int tsr_corpus_destroy(tsr_corpus *corpus);
 int tsr_corpus_score(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *corpus, int flags); /* async */
+/* detect(E_n, W_m) + c_m of EVERY template at every frame of a resident corpus -> per_template
+ * f32 [M, sum T_n] on the host (what tsr_score_bank_all_u8 returns, without re-uploading the features). */
+int tsr_corpus_score_all(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *corpus, int flags, float *per_template);
 int tsr_corpus_download(tsr_ctx *ctx, const tsr_corpus *corpus, float *scores, int32_t *ids);
 int tsr_corpus_frames(const tsr_corpus *corpus, int64_t *total_frames);
 

@@ -493,3 +493,20 @@ def get_edge_features(S, block_length=40, spread_length=1, threshold=.7, abst_th
     E = edge_map_no_threshold(S)
     edge_map_threshold_segments(E, block_length, spread_length, threshold, abst_threshold)
     return reorg_part_for_fast_filtering(E).astype(np.uint8)
+
+
+# ---- Bernoulli mixture E-step, restated from text in f64 ("parity unpinned": the
+# reference evaluates it with a float32 BLAS product whose summation order is not defined).
+def template_loglikelihoods(data_mat, log_templates, log_invtemplates):
+    """bernoulli_mixture.py:287-291 in float64."""
+    X = np.asarray(data_mat, np.float64)
+    return X @ np.asarray(log_templates, np.float64).T + (1 - X) @ np.asarray(log_invtemplates, np.float64).T
+
+
+def mixture_e_step(data_mat, log_templates, log_invtemplates, weights):
+    """bernoulli_mixture.py:263-280 (soft assignment) -> (loglikelihood, affinities f64)."""
+    ll = template_loglikelihoods(data_mat, log_templates, log_invtemplates) + np.log(np.asarray(weights, np.float64))
+    mx = ll.max(1)
+    adj = np.exp(ll - mx[:, None]).sum(1)
+    aff = np.exp(ll - (np.log(adj) + mx)[:, None])
+    return float(np.log(adj).sum() + mx.sum()), aff / aff.sum(1, keepdims=True)

@@ -436,6 +436,20 @@ TSR_API int tsr_corpus_score(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp,
     return corpus_score_impl(ctx, bank, cp, flags, nullptr);
 }
 
+TSR_API int tsr_corpus_score_all(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int flags, float *per_template)
+{
+    TSR_REQUIRE(ctx && bank && cp && (per_template || cp->P == 0), "tsr_corpus_score_all: null pointer");
+    if (cp->P == 0) return TSR_OK;
+    TSR_HIP(hipSetDevice(ctx->device));
+    void *d_all = nullptr;
+    const size_t bytes = (size_t)bank->M * cp->P * sizeof(float);
+    TSR_TRY(tsr_scratch(ctx, SLOT_OUT, bytes, &d_all));
+    TSR_TRY(corpus_score_impl(ctx, bank, cp, flags, (float *)d_all));
+    TSR_HIP(hipMemcpyAsync(per_template, d_all, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    return TSR_OK;
+}
+
 TSR_API int tsr_corpus_download(tsr_ctx *ctx, const tsr_corpus *cp, float *scores, int32_t *ids)
 {
     TSR_REQUIRE(ctx && cp, "tsr_corpus_download: null pointer");

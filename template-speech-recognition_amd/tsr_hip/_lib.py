@@ -38,6 +38,7 @@ SIGNATURES = {
     "tsr_corpus_create": [_p, _p, _p, _i64, _i64, _pp],
     "tsr_corpus_destroy": [_p],
     "tsr_corpus_score": [_p, _p, _p, _int],
+    "tsr_corpus_score_all": [_p, _p, _p, _int, _p],
     "tsr_corpus_download": [_p, _p, _p, _p],
     "tsr_corpus_frames": [_p, C.POINTER(_i64)],
     "tsr_code_parts": [_p, _p, _i64, _i64, _i64, _p, _p, _i64, _i64, _i64, _int, _int, _p],

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import TSR_EXACT, TSR_FAST, check, lib, ptr
+from ._lib import TSR_EXACT, TSR_FAST, TSR_W24, check, lib, ptr
 
 _default_ctx = None
 
@@ -283,6 +283,12 @@ class Corpus:
         check(lib().tsr_corpus_classify_isolated(self.ctx._h, bank._h, self._h, ptr(bgd), ptr(a[0]), ptr(a[1]), ptr(a[2]),
                                                  ptr(b[0]), ptr(b[1]), W, ptr(score), ptr(loc), ptr(tid)))
         return score, loc, tid
+
+    def score_all(self, bank, flags=TSR_EXACT):
+        """detect + c of every template at every frame of the resident corpus -> f32 [M, P]."""
+        out = np.empty((bank.M, self.P), np.float32)
+        check(lib().tsr_corpus_score_all(self.ctx._h, bank._h, self._h, int(flags), ptr(out)))
+        return out
 
     def download(self):
         scores = np.empty(self.P, np.float32)

@@ -675,3 +675,34 @@ def test_fast_error_bound_and_short_filter_promotion(mods, oracle):
     assert np.array_equal(a, b)
     exact = bank.score_all(c["feats"], c["offsets"], flags=tsr_hip.TSR_EXACT)
     assert rel_err(a, exact) <= TOL
+
+
+# ---- Bernoulli-mixture E-step on the bank scorer ------------------------------------
+def test_bernoulli_mixture_e_step_and_em(mods, oracle):
+    import template_speech_rec.bernoulli_mixture as bm
+    rng = np.random.default_rng(14)
+    N, shape, Kmix = 600, (6, 5, 8), 3
+    protos = rng.uniform(0.05, 0.95, size=(Kmix,) + shape)
+    comp = rng.integers(Kmix, size=N)
+    data = (rng.random((N,) + shape) < protos[comp]).astype(np.uint8)
+    mix = bm.BernoulliMixture(Kmix, data, min_probability=0.05)
+    assert mix.data_length == 240 and mix.affinities.shape == (N, Kmix)
+    got = mix.get_template_loglikelihoods()
+    want = oracle.template_loglikelihoods(mix.data_mat, mix.log_templates, mix.log_invtemplates)
+    assert got.shape == (N, Kmix)
+    assert np.max(np.abs(got - want) / np.abs(want)) < 2e-6          # 23-bit weights, f32 output
+    ll = mix._compute_loglikelihoods()
+    ll_ref, aff_ref = oracle.mixture_e_step(mix.data_mat, mix.log_templates, mix.log_invtemplates, mix.weights)
+    assert abs(ll - ll_ref) <= 1e-5 * abs(ll_ref)
+    assert np.max(np.abs(mix.affinities - aff_ref)) < 1e-3
+    final = mix.run_EM(1e-6, min_probability=0.05, max_iter=40, min_iter=5)
+    assert np.isfinite(final) and mix.templates.shape == (Kmix,) + shape and mix.iterations >= 5
+    # the planted components are recovered (up to a permutation)
+    found = mix.templates.reshape(Kmix, -1)
+    cost = np.abs(found[:, None, :] - protos.reshape(Kmix, -1)[None, :, :]).mean(2)
+    assert sorted(cost.argmin(1).tolist()) == list(range(Kmix)) and cost.min(1).max() < 0.08
+    # a deterministic f64 EM from the same start follows the same likelihood path
+    ref = bm.BernoulliMixture(Kmix, data, min_probability=0.05)
+    ref.get_template_loglikelihoods = lambda: oracle.template_loglikelihoods(ref.data_mat, ref.log_templates, ref.log_invtemplates)
+    final_ref = ref.run_EM(1e-6, min_probability=0.05, max_iter=40, min_iter=5)
+    assert abs(final - final_ref) <= 1e-4 * abs(final_ref)
