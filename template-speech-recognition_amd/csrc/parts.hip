@@ -298,6 +298,40 @@ __global__ __launch_bounds__(64 * kSpreadWaves) void spread_mask_kernel(
 }
 }  // namespace
 
+// Geometry of the output stream: output frame q of utterance n is source row beg[n] + (q - ooff[n]) * g0,
+// its dilation window is clipped to the utterance's rows [beg[n], beg[n] + n0[n]).
+namespace {
+__global__ __launch_bounds__(256) void out_geometry_kernel(const int64_t *__restrict__ ooff, const int32_t *__restrict__ beg,
+                                                           const int32_t *__restrict__ n0, int64_t N, int g0, int64_t P_out,
+                                                           int32_t *__restrict__ src_row, int32_t *__restrict__ src_lo,
+                                                           int32_t *__restrict__ src_hi)
+{
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= P_out) return;
+    int64_t lo = 0, hi = N;  // last n with ooff[n] <= q
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (ooff[mid] <= q)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    src_row[q] = beg[lo] + (int32_t)(q - ooff[lo]) * g0;
+    src_lo[q] = beg[lo];
+    src_hi[q] = beg[lo] + n0[lo];
+}
+}  // namespace
+
+int tsr_launch_out_geometry(tsr_ctx *ctx, const int64_t *d_ooff, const int32_t *d_beg, const int32_t *d_n0, int64_t N,
+                            int g0, int64_t P_out, int32_t *d_src_row, int32_t *d_src_lo, int32_t *d_src_hi)
+{
+    if (P_out <= 0) return TSR_OK;
+    hipLaunchKernelGGL(out_geometry_kernel, dim3((unsigned)((P_out + 255) / 256)), dim3(256), 0, ctx->stream, d_ooff, d_beg,
+                       d_n0, N, g0, P_out, d_src_row, d_src_lo, d_src_hi);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+
 // `d_out` rows need no zeroing when this returns with *wrote_all = true (mask kernel); the
 // byte-scatter kernel (K > 64) needs them zeroed and does that itself.
 int tsr_launch_spread_stream(tsr_ctx *ctx, const int32_t *d_A, int64_t N1, int r0, int r1, int64_t K,

@@ -1097,31 +1097,28 @@ TSR_API int tsr_corpus_part_features(tsr_ctx *ctx, const tsr_parts *parts, const
         ooff[n + 1] = ooff[n] + (N0 + g0 - 1) / g0;
     }
     const int64_t P_out = ooff[N];
-    std::vector<int32_t> src_row((size_t)P_out), src_lo((size_t)P_out), src_hi((size_t)P_out);
+    std::vector<int32_t> ubeg((size_t)std::max<int64_t>(N, 1)), un0((size_t)std::max<int64_t>(N, 1));
     for (int64_t n = 0; n < N; ++n) {
-        const int64_t beg = edges->offsets[n], T = edges->offsets[n + 1] - beg;
-        const int64_t N0 = T >= parts->P0 ? T - parts->P0 + 1 : 0;
-        for (int64_t q = ooff[n]; q < ooff[n + 1]; ++q) {
-            src_row[(size_t)q] = (int32_t)(beg + (q - ooff[n]) * g0);
-            src_lo[(size_t)q] = (int32_t)beg;
-            src_hi[(size_t)q] = (int32_t)(beg + N0);
-        }
+        const int64_t T = edges->offsets[n + 1] - edges->offsets[n];
+        ubeg[(size_t)n] = (int32_t)edges->offsets[n];
+        un0[(size_t)n] = (int32_t)(T >= parts->P0 ? T - parts->P0 + 1 : 0);
     }
     // the output corpus object (features are produced on the device, not uploaded)
     tsr_corpus *cp = nullptr;
-    {
-        std::vector<uint8_t> none;
-        TSR_TRY(tsr_corpus_create_empty(ctx, ooff.data(), N, O1 * K, &cp));
-    }
-    void *dA = nullptr, *dRow = nullptr, *dG = nullptr, *dGm = nullptr;
+    TSR_TRY(tsr_corpus_create_empty(ctx, ooff.data(), N, O1 * K, &cp));
+    void *dA = nullptr, *dRow = nullptr, *dG = nullptr, *dGm = nullptr, *dGeo = nullptr;
     int s = tsr_scratch(ctx, SLOT_AUX, (size_t)std::max<int64_t>(edges->P * N1, 1) * 4, &dA);
     if (s == TSR_OK) s = tsr_scratch(ctx, SLOT_W, (size_t)std::max<int64_t>(P_out, 1) * 12, &dRow);
+    if (s == TSR_OK) s = tsr_scratch(ctx, SLOT_IN, (size_t)(N + 1) * 8 + (size_t)std::max<int64_t>(N, 1) * 8, &dGeo);
     int32_t *d_src_row = (int32_t *)dRow, *d_src_lo = d_src_row + P_out, *d_src_hi = d_src_lo + P_out;
-    if (s == TSR_OK && P_out > 0) {
-        if (hipMemcpyAsync(d_src_row, src_row.data(), (size_t)P_out * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(d_src_lo, src_lo.data(), (size_t)P_out * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(d_src_hi, src_hi.data(), (size_t)P_out * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+    if (s == TSR_OK && P_out > 0) {  // per-utterance tables up, per-frame tables made on the device
+        int64_t *d_ooff = (int64_t *)dGeo;
+        int32_t *d_beg = (int32_t *)(d_ooff + N + 1), *d_n0 = d_beg + N;
+        if (hipMemcpyAsync(d_ooff, ooff.data(), (size_t)(N + 1) * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(d_beg, ubeg.data(), (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(d_n0, un0.data(), (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
             s = TSR_ERR_HIP;
+        if (s == TSR_OK) s = tsr_launch_out_geometry(ctx, d_ooff, d_beg, d_n0, N, g0, P_out, d_src_row, d_src_lo, d_src_hi);
     }
     std::vector<uint64_t> gmasks;  // graph rows as part masks (K <= 64), behind the K*K bytes
     if (s == TSR_OK && graph) {

@@ -144,6 +144,8 @@ int tsr_launch_detect_f32(tsr_ctx *ctx, const float *d_F, int64_t T, int64_t D, 
 int tsr_launch_max_detect_examples(tsr_ctx *ctx, const uint8_t *d_F, int64_t N, int64_t T,
                                    int64_t D, const double *d_LF, int64_t L,
                                    const int64_t *d_lengths, double *d_tmp, double *d_out);
+int tsr_launch_out_geometry(tsr_ctx *ctx, const int64_t *d_ooff, const int32_t *d_beg, const int32_t *d_n0, int64_t N,
+                            int g0, int64_t P_out, int32_t *d_src_row, int32_t *d_src_lo, int32_t *d_src_hi);
 // classify.hip
 int tsr_launch_window_argmax(tsr_ctx *ctx, const float *d_all, int64_t stride, int M, const int64_t *d_starts,
                              const int64_t *d_ends, int64_t W, float *d_score, int64_t *d_loc, int32_t *d_tid);
