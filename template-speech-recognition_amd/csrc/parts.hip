@@ -296,6 +296,126 @@ __global__ __launch_bounds__(64 * kSpreadWaves) void spread_mask_kernel(
         *reinterpret_cast<uint4 *>(row + ci * 16) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
+// The same dilation, FB consecutive output frames per wave: their source rows overlap (frame q needs rows
+// src_row[q] +- r0), so the one-hot rows are loaded once per group and first dilated along the columns into
+// registers (cm[row] per lane = column), after which every frame ORs its own <= 2*r0+1 rows.  Waves work
+// independently (own LDS strip, wave-level fences only).  A group whose frames straddle an utterance
+// boundary so that more than kSpreadRows rows would be needed is processed frame by frame.
+constexpr int kSpreadFB = 4;
+constexpr int kSpreadRows = 12;
+
+__global__ __launch_bounds__(64 * kSpreadWaves) void spread_mask_multi_kernel(
+    const int32_t *__restrict__ A, int N1, int r0, int r1, int K, int g1, int O1, int64_t P_out,
+    const int32_t *__restrict__ out_src_row, const int32_t *__restrict__ out_src_lo,
+    const int32_t *__restrict__ out_src_hi, const uint64_t *__restrict__ graph_masks /*[K] or null*/, int Dp_out,
+    uint8_t *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t sp_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwords = (Dp_out >> 5) + 3;
+    const size_t per_wave = ((size_t)kSpreadRows * N1 * 8 + (size_t)kSpreadFB * nwords * 4 + 7) / 8 * 8;
+    uint64_t *bits = reinterpret_cast<uint64_t *>(sp_smem + (size_t)wave * per_wave);  // [kSpreadRows][N1]
+    uint32_t *streams = reinterpret_cast<uint32_t *>(bits + (size_t)kSpreadRows * N1);  // [FB][nwords]
+    const int64_t q0 = ((int64_t)blockIdx.x * kSpreadWaves + wave) * kSpreadFB;
+    if (q0 >= P_out) return;
+    const int nf = (int)min((int64_t)kSpreadFB, P_out - q0);
+    // per-frame row ranges (lane f holds frame f's), wave-uniform copies via readlane
+    int my_lo = 0, my_hi = 0;
+    if (lane < nf) {
+        const int i = out_src_row[q0 + lane];
+        my_lo = max(i - r0, out_src_lo[q0 + lane]);
+        my_hi = min(i + r0 + 1, out_src_hi[q0 + lane]);
+        if (my_hi < my_lo) my_hi = my_lo;
+    }
+    int flo[kSpreadFB], fhi[kSpreadFB];
+    int rmin = 0x7fffffff, rmax = -0x7fffffff;
+#pragma unroll
+    for (int f = 0; f < kSpreadFB; ++f) {
+        flo[f] = __builtin_amdgcn_readlane(my_lo, f);
+        fhi[f] = __builtin_amdgcn_readlane(my_hi, f);
+        if (f < nf && fhi[f] > flo[f]) {
+            rmin = min(rmin, flo[f]);
+            rmax = max(rmax, fhi[f]);
+        }
+    }
+    const bool together = rmax - rmin <= kSpreadRows;
+    const int ngroups = together ? 1 : nf;
+    for (int g = 0; g < ngroups; ++g) {
+        const int f_beg = together ? 0 : g, f_end = together ? nf : g + 1;
+        int gmin = rmin, gmax = rmax;
+        if (!together) {
+            gmin = 0;
+            gmax = 0;
+#pragma unroll
+            for (int f = 0; f < kSpreadFB; ++f)
+                if (f == g) {
+                    gmin = flo[f];
+                    gmax = fhi[f];
+                }
+        }
+        const int nrows = max(gmax - gmin, 0);
+        // ---- one-hot rows of the group -> LDS; zero the frames' bit streams ---------------------------
+        for (int x0 = 0; x0 < nrows; ++x0)
+            for (int c = lane; c < N1; c += 64) {
+                const int p = A[(int64_t)(gmin + x0) * N1 + c];
+                bits[x0 * N1 + c] = p > 0 ? 1ull << (p - 1) : 0ull;
+            }
+        for (int w = lane; w < kSpreadFB * nwords; w += 64) streams[w] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int oj0 = 0; oj0 < O1; oj0 += 64) {
+            const int oj = oj0 + lane;
+            const bool col_on = oj < O1;
+            const int j = oj * g1;
+            const int lo1 = max(j - r1, 0), hi1 = min(j + r1 + 1, N1);
+            uint64_t cm[kSpreadRows];  // column-dilated rows of this lane's output column
+#pragma unroll
+            for (int x0 = 0; x0 < kSpreadRows; ++x0) {
+                uint64_t m = 0;
+                if (col_on && x0 < nrows)
+                    for (int x1 = lo1; x1 < hi1; ++x1) m |= bits[x0 * N1 + x1];
+                cm[x0] = m;
+            }
+#pragma unroll
+            for (int f = 0; f < kSpreadFB; ++f) {
+                if (f < f_beg || f >= f_end) continue;
+                const int a0 = flo[f] - gmin, a1 = fhi[f] - gmin;
+                uint64_t m = 0;
+#pragma unroll
+                for (int x0 = 0; x0 < kSpreadRows; ++x0)
+                    if (x0 >= a0 && x0 < a1) m |= cm[x0];
+                if (graph_masks)
+                    for (int a = 0; a < K; ++a)
+                        if ((m >> a) & 1) m |= graph_masks[a];
+                if (col_on) {  // the K bits at bit offset oj*K of frame f's stream
+                    const int off = oj * K, sh = off & 31;
+                    const uint64_t lo = m << sh;
+                    uint32_t *w = streams + f * nwords + (off >> 5);
+                    if ((uint32_t)lo) atomicOr(w, (uint32_t)lo);
+                    if ((uint32_t)(lo >> 32)) atomicOr(w + 1, (uint32_t)(lo >> 32));
+                    if (sh && (uint32_t)(m >> (64 - sh))) atomicOr(w + 2, (uint32_t)(m >> (64 - sh)));
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- expand the streams to bytes: whole 16-byte chunks of the frames' rows ----------------------
+        for (int f = f_beg; f < f_end; ++f) {
+            uint8_t *row = out + (q0 + f) * Dp_out;
+            const uint16_t *stream16 = reinterpret_cast<const uint16_t *>(streams + f * nwords);
+            for (int ci = lane; ci * 16 < Dp_out; ci += 64) {
+                const uint32_t b = stream16[ci];
+                uint32_t w[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w[q] = (((b >> (4 * q)) & 0xfu) * 0x00204081u) & 0x01010101u;
+                *reinterpret_cast<uint4 *>(row + ci * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the strip is rewritten by the next group
+    }
+}
 }  // namespace
 
 // Geometry of the output stream: output frame q of utterance n is source row beg[n] + (q - ooff[n]) * g0,
@@ -344,6 +464,15 @@ int tsr_launch_spread_stream(tsr_ctx *ctx, const int32_t *d_A, int64_t N1, int r
     if (n <= 0) return TSR_OK;
     const size_t per_wave = ((size_t)(2 * r0 + 1) * N1 * 8 + ((size_t)(Dp_out >> 5) + 3) * 4 + 7) / 8 * 8;
     const size_t lds = (size_t)kSpreadWaves * per_wave;
+    const size_t per_wave_m = ((size_t)kSpreadRows * N1 * 8 + (size_t)kSpreadFB * ((size_t)(Dp_out >> 5) + 3) * 4 + 7) / 8 * 8;
+    if (K <= 64 && 2 * r0 + 1 <= kSpreadRows && kSpreadWaves * per_wave_m <= 64 * 1024 && Dp_out % 16 == 0) {
+        const int64_t frames_per_block = (int64_t)kSpreadWaves * kSpreadFB;
+        hipLaunchKernelGGL(spread_mask_multi_kernel, dim3((unsigned)((P_out + frames_per_block - 1) / frames_per_block)),
+                           dim3(64 * kSpreadWaves), kSpreadWaves * per_wave_m, ctx->stream, d_A, (int)N1, r0, r1, (int)K, g1,
+                           (int)O1, P_out, d_src_row, d_src_lo, d_src_hi, d_graph ? d_graph_masks : nullptr, Dp_out, d_out);
+        TSR_HIP(hipGetLastError());
+        return TSR_OK;
+    }
     if (K <= 64 && lds <= 48 * 1024 && Dp_out % 16 == 0) {
         hipLaunchKernelGGL(spread_mask_kernel, dim3((unsigned)((P_out + kSpreadWaves - 1) / kSpreadWaves)),
                            dim3(64 * kSpreadWaves), lds, ctx->stream, d_A, (int)N1, r0, r1, (int)K, g1, (int)O1, P_out,
