@@ -253,6 +253,12 @@ int tsr_edge_corpus_create(tsr_ctx *ctx, const double *S_cat, const int64_t *fra
                            int64_t H, int block_length, int spread_length, double quantile,
                            const double *abst_threshold, tsr_corpus **out);
 
+/* M-step sums of the Bernoulli mixture (bernoulli_mixture.py:179, np.dot(affinities.T, data_mat)) on a
+ * resident binary corpus: out f32 [K, D], out[k][d] = sum_p weights[p][k] * x[p][d], weights f32 [P, K]
+ * (one row per frame).  f32 accumulation in a fixed order (frames ascending inside <= 64 slices, slices
+ * ascending): reproducible, but -- like the reference's BLAS product -- not a defined reference order. */
+int tsr_corpus_weighted_sums(tsr_ctx *ctx, const tsr_corpus *corpus, const float *weights, int64_t K, float *out);
+
 /* ---- multi-GPU: utterances shard across ranks, the bank is broadcast once ----- */
 /* One process per GPU.  Rank 0 calls tsr_dist_unique_id and hands the 128 bytes
  * to the other ranks over any host channel; every rank then calls

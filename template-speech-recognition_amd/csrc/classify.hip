@@ -300,3 +300,60 @@ int tsr_launch_window_peak_max(tsr_ctx *ctx, const float *d_v, const int64_t *d_
     TSR_HIP(hipGetLastError());
     return TSR_OK;
 }
+
+// ---- Bernoulli-mixture M-step sums: out[k][d] = sum_n aff[n][k] * x[n][d] ------------
+// bernoulli_mixture.py:179 (np.dot(affinities.T, data_mat)) on the resident binary corpus: one lane per
+// feature d (coalesced byte reads of frame n), KC components per lane, frames split over gridDim.y
+// slices whose partial sums are added in slice order by the second kernel (deterministic).
+namespace {
+constexpr int kMK = 8;
+__global__ __launch_bounds__(kThreads) void mstep_partial_kernel(const uint8_t *__restrict__ X, int64_t P, int D, int Dp,
+                                                                 const float *__restrict__ aff /*[P][K]*/, int K, int k0,
+                                                                 int64_t rows_per_slice, float *__restrict__ part /*[S][K][D]*/)
+{
+    const int d = blockIdx.x * kThreads + threadIdx.x;
+    const int64_t n0 = (int64_t)blockIdx.y * rows_per_slice, n1 = min(P, n0 + rows_per_slice);
+    float acc[kMK];
+#pragma unroll
+    for (int j = 0; j < kMK; ++j) acc[j] = 0.0f;
+    if (d < D)
+        for (int64_t n = n0; n < n1; ++n) {
+            const float x = (float)X[n * Dp + d];
+            const float *a = aff + n * K + k0;  // wave-uniform
+#pragma unroll
+            for (int j = 0; j < kMK; ++j)
+                if (k0 + j < K) acc[j] = __builtin_fmaf(a[j], x, acc[j]);
+        }
+    if (d < D)
+#pragma unroll
+        for (int j = 0; j < kMK; ++j)
+            if (k0 + j < K) part[((int64_t)blockIdx.y * K + k0 + j) * D + d] = acc[j];
+}
+
+__global__ __launch_bounds__(kThreads) void mstep_reduce_kernel(const float *__restrict__ part, int S, int64_t KD,
+                                                                float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= KD) return;
+    float s = 0.0f;
+    for (int sl = 0; sl < S; ++sl) s += part[(int64_t)sl * KD + i];
+    out[i] = s;
+}
+}  // namespace
+
+int tsr_launch_mstep(tsr_ctx *ctx, const uint8_t *d_X, int64_t P, int D, int Dp, const float *d_aff, int K,
+                     float *d_part, int S, float *d_out)
+{
+    if (P <= 0 || K <= 0) return TSR_OK;
+    const int64_t rows_per_slice = (P + S - 1) / S;
+    for (int k0 = 0; k0 < K; k0 += kMK) {
+        hipLaunchKernelGGL(mstep_partial_kernel, dim3((unsigned)((D + kThreads - 1) / kThreads), (unsigned)S), dim3(kThreads), 0,
+                           ctx->stream, d_X, P, D, Dp, d_aff, K, k0, rows_per_slice, d_part);
+        TSR_HIP(hipGetLastError());
+    }
+    const int64_t KD = (int64_t)K * D;
+    hipLaunchKernelGGL(mstep_reduce_kernel, dim3((unsigned)((KD + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream,
+                       d_part, S, KD, d_out);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}

@@ -791,6 +791,29 @@ TSR_API int tsr_edge_corpus_create(tsr_ctx *ctx, const double *S_cat, const int6
     return TSR_OK;
 }
 
+// ---- Bernoulli-mixture M-step sums --------------------------------------
+TSR_API int tsr_corpus_weighted_sums(tsr_ctx *ctx, const tsr_corpus *cp, const float *weights, int64_t K, float *out)
+{
+    TSR_REQUIRE(ctx && cp && weights && out, "tsr_corpus_weighted_sums: null pointer");
+    TSR_REQUIRE(K >= 1 && K <= 4096, "tsr_corpus_weighted_sums: K=%lld out of range", (long long)K);
+    const int64_t P = cp->P, D = cp->D;
+    if (P == 0) {
+        memset(out, 0, (size_t)(K * D) * sizeof(float));
+        return TSR_OK;
+    }
+    TSR_HIP(hipSetDevice(ctx->device));
+    const int S = (int)std::max<int64_t>(1, std::min<int64_t>(64, P / 64));  // frame slices (fixed reduction order)
+    void *dA = nullptr, *dP = nullptr, *dO = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_IN, (size_t)(P * K) * 4, &dA));
+    TSR_TRY(tsr_scratch(ctx, SLOT_RAW, (size_t)S * K * D * 4, &dP));
+    TSR_TRY(tsr_scratch(ctx, SLOT_OUT, (size_t)(K * D) * 4, &dO));
+    TSR_HIP(hipMemcpyAsync(dA, weights, (size_t)(P * K) * 4, hipMemcpyHostToDevice, ctx->stream));
+    TSR_TRY(tsr_launch_mstep(ctx, cp->d_feats, P, (int)D, cp->Dp, (const float *)dA, (int)K, (float *)dP, S, (float *)dO));
+    TSR_HIP(hipMemcpyAsync(out, dO, (size_t)(K * D) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    return TSR_OK;
+}
+
 // ---- single-utterance drop-ins ----------------------------------------------------
 TSR_API int tsr_detect_u8(tsr_ctx *ctx, const uint8_t *F, int64_t T, int64_t D, const float *LF,
                           int64_t L, float *out)

@@ -11,8 +11,8 @@ sum_d x[n, d] * (log_templates - log_invtemplates)[k, d].  It runs on the matrix
 accumulation of 23-bit fixed-point weights (TSR_FAST | TSR_W24); the data matrix is uploaded once and
 stays resident across the EM iterations.  The reference evaluates the same expression with a float32
 BLAS product, so the two agree to float32 rounding, not bit for bit (no summation order is defined
-there).  The M-step (affinities^T . data_mat) and the bookkeeping stay NumPy expressions, as in the
-reference.
+there).  The M-step product affinities^T . data_mat (:179) runs on the same resident matrix
+(tsr_corpus_weighted_sums); the bookkeeping stays the reference's NumPy expressions.
 """
 import collections
 
@@ -101,7 +101,7 @@ class BernoulliMixture:
 
     def M_step(self):
         self.weights = np.mean(self.affinities, axis=0)
-        self.work_templates = np.dot(self.affinities.T, self.data_mat).astype(np.float32)
+        self.work_templates = self._corpus.weighted_sums(self.affinities)   # np.dot(affinities.T, data_mat), :179
         self.work_templates /= self.num_data
         self.work_templates /= self.weights.reshape((self.num_mix, 1))
         self.threshold_templates()

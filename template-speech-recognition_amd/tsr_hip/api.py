@@ -290,6 +290,16 @@ class Corpus:
         check(lib().tsr_corpus_score_all(self.ctx._h, bank._h, self._h, int(flags), ptr(out)))
         return out
 
+    def weighted_sums(self, weights):
+        """sum_p weights[p, k] * x[p, :] for every column k of `weights` f32 [P, K] -> f32 [K, D]
+        (the M-step product of the Bernoulli mixture, bernoulli_mixture.py:179)."""
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        if w.ndim != 2 or w.shape[0] != self.P:
+            raise ValueError("weights must be [P, K]")
+        out = np.empty((w.shape[1], self.D), np.float32)
+        check(lib().tsr_corpus_weighted_sums(self.ctx._h, self._h, ptr(w), w.shape[1], ptr(out)))
+        return out
+
     def download(self):
         scores = np.empty(self.P, np.float32)
         ids = np.empty(self.P, np.int32)

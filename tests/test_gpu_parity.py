@@ -695,6 +695,9 @@ def test_bernoulli_mixture_e_step_and_em(mods, oracle):
     ll_ref, aff_ref = oracle.mixture_e_step(mix.data_mat, mix.log_templates, mix.log_invtemplates, mix.weights)
     assert abs(ll - ll_ref) <= 1e-5 * abs(ll_ref)
     assert np.max(np.abs(mix.affinities - aff_ref)) < 1e-3
+    ws = mix._corpus.weighted_sums(mix.affinities)                    # the M-step product on the device
+    ws_ref = mix.affinities.astype(np.float64).T @ mix.data_mat.astype(np.float64)
+    assert ws.shape == (Kmix, 240) and np.max(np.abs(ws - ws_ref) / np.maximum(np.abs(ws_ref), 1.0)) < 1e-5
     final = mix.run_EM(1e-6, min_probability=0.05, max_iter=40, min_iter=5)
     assert np.isfinite(final) and mix.templates.shape == (Kmix,) + shape and mix.iterations >= 5
     # the planted components are recovered (up to a permutation)
@@ -704,5 +707,9 @@ def test_bernoulli_mixture_e_step_and_em(mods, oracle):
     # a deterministic f64 EM from the same start follows the same likelihood path
     ref = bm.BernoulliMixture(Kmix, data, min_probability=0.05)
     ref.get_template_loglikelihoods = lambda: oracle.template_loglikelihoods(ref.data_mat, ref.log_templates, ref.log_invtemplates)
+    class _HostSums:                                                   # ... and a NumPy M-step product
+        def weighted_sums(self, w):
+            return (np.asarray(w, np.float64).T @ ref.data_mat.astype(np.float64)).astype(np.float32)
+    ref._corpus = _HostSums()
     final_ref = ref.run_EM(1e-6, min_probability=0.05, max_iter=40, min_iter=5)
     assert abs(final - final_ref) <= 1e-4 * abs(final_ref)

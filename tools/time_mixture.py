@@ -20,3 +20,11 @@ print("E-step scoring, %d examples x D=%d x %d components: device %.2f ms (bank 
       % (N, mix.data_length, K, (t1 - t0) * 1e3, (t3 - t2) * 1e3))
 print("max relative deviation from the float64 value: device %.2e, NumPy float32 %.2e"
       % (np.max(np.abs(got - ref64) / np.abs(ref64)), np.max(np.abs(ref - ref64) / np.abs(ref64))))
+mix._compute_loglikelihoods()
+for _ in range(2):
+    t0 = time.perf_counter(); ws = mix._corpus.weighted_sums(mix.affinities); t1 = time.perf_counter()
+t2 = time.perf_counter(); ws_np = np.dot(mix.affinities.T, mix.data_mat).astype(np.float32); t3 = time.perf_counter()
+ws64 = mix.affinities.astype(np.float64).T @ mix.data_mat.astype(np.float64)
+print("M-step product affinities^T . data: device %.2f ms (upload of the affinities + kernels + download), NumPy %.1f ms; "
+      "max deviation from float64 relative to the value: device %.1e, NumPy %.1e"
+      % ((t1 - t0) * 1e3, (t3 - t2) * 1e3, np.max(np.abs(ws - ws64) / np.maximum(ws64, 1)), np.max(np.abs(ws_np - ws64) / np.maximum(ws64, 1))))
