@@ -139,7 +139,8 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N")
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
-    ctx = tsr_hip.Context(local_rank)
+    # (TSR_DEVICE pins every rank to one GPU: a rehearsal of the N > 1 control flow on a one-GPU box)
+    ctx = tsr_hip.Context(int(os.environ.get("TSR_DEVICE", local_rank)))
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # launched by torch.distributed.run
         import torch.distributed as dist  # host control plane only (gloo, CPU tensors)
