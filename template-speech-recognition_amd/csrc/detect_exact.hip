@@ -152,25 +152,76 @@ __global__ __launch_bounds__(kThreads) void bank_epilogue_kernel(
 // compute_likelihood_linear_filter.pyx:178-219 / :221-278 / :281-359: f32
 // features, product rounded to f32 then added (no FMA contraction), accumulator
 // initialised to cs[m] when given.  One thread per (template, window).
-__global__ __launch_bounds__(kThreads) void detect_f32_kernel(
+__global__ __launch_bounds__(64) void detect_f32_kernel(
     const float *__restrict__ F, int T, int D, const float *__restrict__ LF, int M, int L,
     const float *__restrict__ cs, float *__restrict__ out)
 {
 #pragma clang fp contract(off)  // the reference rounds the product to f32 before the add
-    const int t = blockIdx.x * kThreads + threadIdx.x;
+    const int t = blockIdx.x * 64 + threadIdx.x;
     const int m = blockIdx.y;
     if (t >= T) return;
     float acc = 0.0f;
     if (t + L <= T) {
         acc = cs ? cs[m] : 0.0f;
-        const float *__restrict__ w = LF + (int64_t)m * L * D;
+        const float *__restrict__ w = LF + (int64_t)m * L * D;   // wave-uniform: scalar loads
         const float *__restrict__ f = F + (int64_t)t * D;
-        for (int k = 0; k < L * D; ++k) {
+        const int n = L * D;
+        int k = 0;
+        if ((D & 3) == 0) {  // rows are 16-byte multiples: four features per load, 16 in flight
+            for (; k + 16 <= n; k += 16) {
+                float4 x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const float4 *>(f + k + 4 * u);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float prod = w[k + 4 * u + j] * xs[j];
+                        acc = acc + prod;
+                    }
+                }
+            }
+        }
+        for (; k < n; ++k) {
             const float prod = w[k] * f[k];
             acc = acc + prod;
         }
     }
     out[(int64_t)m * T + t] = acc;
+}
+
+// detect (compute_likelihood_linear_filter.pyx:135-176) for ONE utterance and ONE filter straight from
+// the caller's packed bytes: the per-call drop-in path (no bank, no corpus object).  One lane per
+// window, the reference's order tau -> d, acc = fma(x, w, acc) with x in {0, 1}.
+__global__ __launch_bounds__(64) void detect_u8_single_kernel(const uint8_t *__restrict__ F, int T, int D,
+                                                              const float *__restrict__ LF, int L,
+                                                              float *__restrict__ out)
+{
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= T) return;
+    float acc = 0.0f;
+    if (t + L <= T) {
+        const uint8_t *__restrict__ f = F + (int64_t)t * D;  // rows t .. t+L-1 are contiguous: L*D bytes
+        const int n = L * D;
+        int k = 0;
+        if ((D & 3) == 0) {  // (vector loads for the bytes, scalar loads for the weights: separate wait counters)
+            for (; k + 16 <= n; k += 16) {
+                uint32_t x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const uint32_t *>(f + k + 4 * u);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xs = ((x[u] >> (8 * j)) & 0xffu) ? 1.0f : 0.0f;
+                        acc = __builtin_fmaf(xs, LF[k + 4 * u + j], acc);
+                    }
+            }
+        }
+        for (; k < n; ++k) acc = __builtin_fmaf(f[k] ? 1.0f : 0.0f, LF[k], acc);
+    }
+    out[t] = acc;
 }
 
 // compute_likelihood_linear_filter.pyx:21-76: f64 sum, filter truncated at the
@@ -236,9 +287,18 @@ int tsr_launch_detect_f32(tsr_ctx *ctx, const float *d_F, int64_t T, int64_t D, 
                           int64_t M, int64_t L, const float *d_cs, float *d_out, uint16_t *d_ids)
 {
     (void)d_ids;
-    dim3 grid((unsigned)((T + kThreads - 1) / kThreads), (unsigned)M);
-    hipLaunchKernelGGL(detect_f32_kernel, grid, dim3(kThreads), 0, ctx->stream, d_F, (int)T, (int)D,
+    dim3 grid((unsigned)((T + 63) / 64), (unsigned)M);
+    hipLaunchKernelGGL(detect_f32_kernel, grid, dim3(64), 0, ctx->stream, d_F, (int)T, (int)D,
                        d_LF, (int)M, (int)L, d_cs, d_out);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+
+int tsr_launch_detect_u8_single(tsr_ctx *ctx, const uint8_t *d_F, int64_t T, int64_t D, const float *d_LF, int64_t L,
+                                float *d_out)
+{
+    hipLaunchKernelGGL(detect_u8_single_kernel, dim3((unsigned)((T + 63) / 64)), dim3(64), 0, ctx->stream, d_F, (int)T,
+                       (int)D, d_LF, (int)L, d_out);
     TSR_HIP(hipGetLastError());
     return TSR_OK;
 }

@@ -93,6 +93,7 @@ TSR_API int tsr_ctx_destroy(tsr_ctx *ctx)
     if (ctx->comm) tsr_dist_finalize(ctx);
     for (auto &b : ctx->scratch)
         if (b.ptr) (void)hipFree(b.ptr);
+    if (ctx->pinned.ptr) (void)hipHostFree(ctx->pinned.ptr);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -147,6 +148,28 @@ int tsr_scratch(tsr_ctx *ctx, int slot, size_t bytes, void **out)
         b.cap = cap;
     }
     *out = b.ptr;
+    return TSR_OK;
+}
+
+int tsr_download(tsr_ctx *ctx, void *dst, const void *d_src, size_t bytes)
+{
+    if (bytes == 0) return TSR_OK;
+    if (bytes < ((size_t)256 << 10) || bytes > ((size_t)256 << 20)) {
+        TSR_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        TSR_HIP(hipStreamSynchronize(ctx->stream));
+        return TSR_OK;
+    }
+    tsr_devbuf &b = ctx->pinned;
+    if (bytes > b.cap) {
+        if (b.ptr) TSR_HIP(hipHostFree(b.ptr));
+        b.ptr = nullptr;
+        b.cap = 0;
+        TSR_HIP(hipHostMalloc(&b.ptr, bytes, hipHostMallocDefault));
+        b.cap = bytes;
+    }
+    TSR_HIP(hipMemcpyAsync(b.ptr, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(dst, b.ptr, bytes);
     return TSR_OK;
 }
 
@@ -445,17 +468,15 @@ TSR_API int tsr_corpus_score_all(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus 
     const size_t bytes = (size_t)bank->M * cp->P * sizeof(float);
     TSR_TRY(tsr_scratch(ctx, SLOT_OUT, bytes, &d_all));
     TSR_TRY(corpus_score_impl(ctx, bank, cp, flags, (float *)d_all));
-    TSR_HIP(hipMemcpyAsync(per_template, d_all, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    TSR_HIP(hipStreamSynchronize(ctx->stream));
-    return TSR_OK;
+    return tsr_download(ctx, per_template, d_all, bytes);
 }
 
 TSR_API int tsr_corpus_download(tsr_ctx *ctx, const tsr_corpus *cp, float *scores, int32_t *ids)
 {
     TSR_REQUIRE(ctx && cp, "tsr_corpus_download: null pointer");
     TSR_HIP(hipSetDevice(ctx->device));
-    if (scores && cp->P) TSR_HIP(hipMemcpyAsync(scores, cp->d_scores, (size_t)cp->P * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (ids && cp->P) TSR_HIP(hipMemcpyAsync(ids, cp->d_ids, (size_t)cp->P * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (scores && cp->P) TSR_TRY(tsr_download(ctx, scores, cp->d_scores, (size_t)cp->P * 4));
+    if (ids && cp->P) TSR_TRY(tsr_download(ctx, ids, cp->d_ids, (size_t)cp->P * 4));
     TSR_HIP(hipStreamSynchronize(ctx->stream));
     return TSR_OK;
 }
@@ -708,7 +729,7 @@ TSR_API int tsr_peaks(tsr_ctx *ctx, const tsr_corpus *cp, const float *vals, con
     TSR_TRY(tsr_scratch(ctx, SLOT_W, (size_t)std::max<int64_t>(total, 1) * 4, &dT));
     TSR_TRY(tsr_launch_peaks(ctx, d_v, d_off, n, threshold, C0, (int64_t *)dC, (int32_t *)dT));
     TSR_HIP(hipMemcpyAsync(counts, dC, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (total) TSR_HIP(hipMemcpyAsync(times, dT, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (total) TSR_TRY(tsr_download(ctx, times, dT, (size_t)total * 4));
     TSR_HIP(hipStreamSynchronize(ctx->stream));
     return TSR_OK;
 }
@@ -820,14 +841,21 @@ TSR_API int tsr_detect_u8(tsr_ctx *ctx, const uint8_t *F, int64_t T, int64_t D, 
 {
     TSR_REQUIRE(ctx && F && LF && out, "tsr_detect_u8: null pointer");
     TSR_REQUIRE(L >= 1 && T >= L, "tsr_detect_u8: need T >= L >= 1 (T=%lld, L=%lld); the reference reads out of bounds here", (long long)T, (long long)L);
-    const int32_t L32 = (int32_t)L;
-    const double c0 = 0.0;
-    const int64_t offs[2] = {0, T};
-    tsr_bank *bank = nullptr;
-    TSR_TRY(tsr_bank_create(ctx, LF, &L32, &c0, 1, D, &bank));
-    int s = tsr_score_bank_all_u8(ctx, bank, F, offs, 1, TSR_EXACT, out);
-    tsr_bank_destroy(bank);
-    return s;
+    TSR_REQUIRE(D >= 1 && T <= 65535 * 64 && L * D < ((int64_t)1 << 31), "tsr_detect_u8: sizes out of range");
+    for (int64_t i = 0; i < L * D; ++i)
+        TSR_REQUIRE(isfinite(LF[i]), "tsr_detect_u8: filter value %lld is not finite", (long long)i);
+    // the per-call path: caller's bytes and filter through the ctx scratch, one small launch
+    TSR_HIP(hipSetDevice(ctx->device));
+    void *dF, *dW, *dO;
+    TSR_TRY(tsr_scratch(ctx, SLOT_IN, (size_t)(T * D) + 16, &dF));
+    TSR_TRY(tsr_scratch(ctx, SLOT_W, (size_t)(L * D) * 4, &dW));
+    TSR_TRY(tsr_scratch(ctx, SLOT_OUT, (size_t)T * 4, &dO));
+    TSR_HIP(hipMemcpyAsync(dF, F, (size_t)(T * D), hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(dW, LF, (size_t)(L * D) * 4, hipMemcpyHostToDevice, ctx->stream));
+    TSR_TRY(tsr_launch_detect_u8_single(ctx, (const uint8_t *)dF, T, D, (const float *)dW, L, (float *)dO));
+    TSR_HIP(hipMemcpyAsync(out, dO, (size_t)T * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    return TSR_OK;
 }
 
 static int detect_f32_common(tsr_ctx *ctx, const float *F, int64_t T, int64_t D, const float *LF,
@@ -996,18 +1024,35 @@ TSR_API int tsr_code_parts(tsr_ctx *ctx, const uint8_t *X, int64_t X0, int64_t X
     TSR_REQUIRE(ctx && X && lp && lip && out, "tsr_code_parts: null pointer");
     TSR_REQUIRE(X0 >= P0 && X1 >= P1 && P0 >= 1 && P1 >= 1, "tsr_code_parts: patch %lldx%lld larger than map %lldx%lld", (long long)P0, (long long)P1, (long long)X0, (long long)X1);
     TSR_REQUIRE(X0 * X1 * E < ((int64_t)1 << 31), "tsr_code_parts: map too large");
-    tsr_parts *parts = nullptr;
-    TSR_TRY(tsr_parts_create(ctx, lp, lip, K, P0, P1, E, &parts));
+    TSR_REQUIRE(K >= 1 && E >= 1 && K <= 65535 && P0 * P1 * E <= (1 << 20), "tsr_code_parts: bad geometry");
+    // one-shot call: the table goes through the ctx scratch (no object, no allocation per call)
+    const int64_t Q = P0 * P1 * E;
+    std::vector<double> tab((size_t)(Q * K * 2));
+    for (int64_t k = 0; k < K; ++k)
+        for (int64_t q = 0; q < Q; ++q) {
+            tab[(size_t)((q * K + k) * 2 + 0)] = lip[k * Q + q];
+            tab[(size_t)((q * K + k) * 2 + 1)] = lp[k * Q + q];
+        }
+    TSR_HIP(hipSetDevice(ctx->device));
     const int64_t n_loc = (X0 - P0 + 1) * (X1 - P1 + 1);
-    void *dX, *dO;
+    void *dX = nullptr, *dO = nullptr, *dT = nullptr;
     int s = tsr_scratch(ctx, SLOT_IN, (size_t)(X0 * X1 * E), &dX);
     if (s == TSR_OK) s = tsr_scratch(ctx, SLOT_OUT, (size_t)(n_loc * (K + 1)) * 8, &dO);
-    if (s == TSR_OK && hipMemcpyAsync(dX, X, (size_t)(X0 * X1 * E), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
-    if (s == TSR_OK) s = tsr_launch_code_parts(ctx, parts, (const uint8_t *)dX, X0, X1, threshold, fast, (double *)dO, nullptr);
-    if (s == TSR_OK && hipMemcpyAsync(out, dO, (size_t)(n_loc * (K + 1)) * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
-    if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
+    if (s == TSR_OK) s = tsr_scratch(ctx, SLOT_W, tab.size() * 8, &dT);
+    tsr_parts tmp;
+    tmp.ctx = ctx;
+    tmp.device = ctx->device;
+    tmp.K = K;
+    tmp.P0 = P0;
+    tmp.P1 = P1;
+    tmp.E = E;
+    tmp.d_tab = (double *)dT;
+    if (s == TSR_OK && (hipMemcpyAsync(dX, X, (size_t)(X0 * X1 * E), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                        hipMemcpyAsync(dT, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess))
+        s = TSR_ERR_HIP;
+    if (s == TSR_OK) s = tsr_launch_code_parts(ctx, &tmp, (const uint8_t *)dX, X0, X1, threshold, fast, (double *)dO, nullptr);
+    if (s == TSR_OK) s = tsr_download(ctx, out, dO, (size_t)(n_loc * (K + 1)) * 8);
     if (s == TSR_ERR_HIP) tsr_set_error("tsr_code_parts: device copy/launch failed");
-    tsr_parts_destroy(parts);
     return s;
 }
 
