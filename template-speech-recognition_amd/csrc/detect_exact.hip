@@ -224,6 +224,59 @@ __global__ __launch_bounds__(64) void detect_u8_single_kernel(const uint8_t *__r
     out[t] = acc;
 }
 
+// The same with both operands in LDS (D a multiple of 8, everything fits): the 64 lanes first copy the
+// block's rows (as 0/1 bytes) and the whole filter, then every lane walks its window's chain with the data
+// of the next 8 features already requested while the current 8 are added -- the chain of L*D dependent
+// f32 additions is latency-bound, so what matters is that nothing but the adds sits on it.
+__global__ __launch_bounds__(64) void detect_u8_single_lds_kernel(const uint8_t *__restrict__ F, int T, int D,
+                                                                  const float *__restrict__ LF, int L, int RS,
+                                                                  float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t du_smem[];
+    const int t0 = blockIdx.x * 64, lane = threadIdx.x;
+    const int nrows = min(64 + L - 1, T - t0);
+    uint8_t *xs = du_smem;                                                        // [nrows][RS]
+    float *ws = reinterpret_cast<float *>(du_smem + (size_t)(64 + L - 1) * RS);   // [L*D]
+    const int D4 = D >> 2;
+    for (int i = lane; i < nrows * D4; i += 64) {
+        const int r = i / D4, c4 = (i - r * D4) * 4;
+        const uint32_t x = *reinterpret_cast<const uint32_t *>(F + (int64_t)(t0 + r) * D + c4);
+        *reinterpret_cast<uint32_t *>(xs + (size_t)r * RS + c4) = ((x | ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu)) >> 7) & 0x01010101u;
+    }
+    for (int i = lane; i < (L * D) >> 2; i += 64) reinterpret_cast<float4 *>(ws)[i] = reinterpret_cast<const float4 *>(LF)[i];
+    __syncthreads();
+    const int t = t0 + lane;
+    if (t >= T) return;
+    float acc = 0.0f;
+    if (t + L <= T) {
+        const int per_row = D >> 3, n8 = L * per_row;  // 8-feature groups (rows are multiples of 8 bytes)
+        auto xaddr = [&](int gidx) { const int tau = gidx / per_row; return xs + (size_t)(lane + tau) * RS + (gidx - tau * per_row) * 8; };
+        uint2 xn = *reinterpret_cast<const uint2 *>(xaddr(0));
+        float4 wn[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) wn[u] = reinterpret_cast<const float4 *>(ws)[u];
+        for (int gidx = 0; gidx < n8; ++gidx) {
+            const uint2 xc = xn;
+            float4 wc[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) wc[u] = wn[u];
+            if (gidx + 1 < n8) {
+                xn = *reinterpret_cast<const uint2 *>(xaddr(gidx + 1));
+#pragma unroll
+                for (int u = 0; u < 2; ++u) wn[u] = reinterpret_cast<const float4 *>(ws)[(gidx + 1) * 2 + u];
+            }
+            const uint32_t xw[2] = {xc.x, xc.y};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float w4[4] = {wc[u].x, wc[u].y, wc[u].z, wc[u].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_fmaf((float)((xw[u] >> (8 * j)) & 0xffu), w4[j], acc);
+            }
+        }
+    }
+    out[t] = acc;
+}
+
 // compute_likelihood_linear_filter.pyx:21-76: f64 sum, filter truncated at the
 // end of the example.  One thread per (example, t); the max over t is taken by
 // the caller with the reference's first-t/strict-'>' rule.
@@ -297,6 +350,19 @@ int tsr_launch_detect_f32(tsr_ctx *ctx, const float *d_F, int64_t T, int64_t D, 
 int tsr_launch_detect_u8_single(tsr_ctx *ctx, const uint8_t *d_F, int64_t T, int64_t D, const float *d_LF, int64_t L,
                                 float *d_out)
 {
+    if ((D & 7) == 0) {
+        int RS = (int)D;
+        if (((RS >> 3) & 1) == 0) RS += 8;  // odd number of 8-byte slots: consecutive rows start in different banks
+        const size_t lds = (size_t)(64 + L - 1) * RS + (size_t)(L * D) * 4;
+        if (lds <= 128 * 1024) {
+            TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_u8_single_lds_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(detect_u8_single_lds_kernel, dim3((unsigned)((T + 63) / 64)), dim3(64), lds, ctx->stream, d_F,
+                               (int)T, (int)D, d_LF, (int)L, RS, d_out);
+            TSR_HIP(hipGetLastError());
+            return TSR_OK;
+        }
+    }
     hipLaunchKernelGGL(detect_u8_single_kernel, dim3((unsigned)((T + 63) / 64)), dim3(64), 0, ctx->stream, d_F, (int)T,
                        (int)D, d_LF, (int)L, d_out);
     TSR_HIP(hipGetLastError());
