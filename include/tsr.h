@@ -61,8 +61,8 @@ enum {
  *              noise of the reference's own sequential f32 sum.  A window whose score is of
  *              order one next to thousands of cancelling taps is NOT within 1e-4 of its own
  *              value in this mode -- nor is the reference's f32 result within that of the
- *              exact sum; ask for TSR_W24 or TSR_EXACT there.  Filters of at most 4096 taps
- *              (Lmax * D) always get the third limb.
+ *              exact sum; ask for TSR_W24 or TSR_EXACT there.  A bank whose shortest filter has at
+ *              most 4096 taps (L * D) always gets the third limb.
  *   TSR_FAST | TSR_W24: three limbs (23-bit weights, power-of-two scale),
  *              <= 2^-22 * max|W_m| per set tap, at 1.5x the matrix-core work. */
 enum { TSR_EXACT = 0, TSR_FAST = 1, TSR_W24 = 2 };

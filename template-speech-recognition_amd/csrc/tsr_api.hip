@@ -435,7 +435,11 @@ static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp,
     // Short filters (few thousand taps) produce scores of order one, against which the 16-bit
     // quantisation noise is no longer small; their launch is latency-bound anyway, so TSR_FAST
     // takes the third limb there at no measurable cost (include/tsr.h, "at least 16-bit weights").
-    if ((flags & TSR_FAST) && (int64_t)bank->Lmax * bank->D <= TSR_FAST_W24_BELOW_TAPS) flags |= TSR_W24;
+    if (flags & TSR_FAST) {
+        int32_t Lmin = bank->Lmax;
+        for (int32_t l : bank->L) Lmin = std::min(Lmin, l);
+        if ((int64_t)Lmin * bank->D <= TSR_FAST_W24_BELOW_TAPS) flags |= TSR_W24;  // (the shortest filter decides)
+    }
     if (flags & TSR_FAST) {
         const int NL = (flags & TSR_W24) ? 3 : 2;
         if (!bank->fast[NL - 2]) {

@@ -72,7 +72,7 @@ int tsr_corpus_create_empty(tsr_ctx *ctx, const int64_t *frame_offsets, int64_t 
 // 32-byte line feeds 8 templates for one feature.
 #define TSR_MG 8
 
-// TSR_FAST uses three limbs when the longest filter has at most this many taps (Lmax * D).
+// TSR_FAST uses three limbs when the SHORTEST filter of the bank has at most this many taps (Lmin * D).
 #define TSR_FAST_W24_BELOW_TAPS 4096
 
 // Fast (MFMA) path: see detect_mfma_kernel.inc for the limb layout.
