@@ -1,6 +1,6 @@
 // Is v_mfma_f32_16x16x4_f32 an exact fmaf chain in ascending k?  D[i][j] = C[i][j] + sum_k A[i][k] B[k][j].
 // Compare, bit for bit, with c = fmaf(a_k, b_k, c) for k = 0..3 (and with other orders) on random data,
-// chained over many K-steps.  hipcc --offload-arch=gfx950 -O2 mfma_f32_chain.hip -o mfma_f32_chain
+// chained over many K-steps.  hipcc --offload-arch=gfx950 -O2 mfma_f32_chain.hip -o mfma_f32_chain.bin
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
