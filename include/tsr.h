@@ -230,6 +230,18 @@ int tsr_corpus_classify_isolated(tsr_ctx *ctx, const tsr_bank *bank, const tsr_c
  * from times[offsets[n]] on (times i32 [offsets[N]]). */
 int tsr_peaks(tsr_ctx *ctx, const tsr_corpus *corpus, const float *vals, const int64_t *offsets, int64_t N,
               float threshold, int C0, int64_t *counts, int32_t *times);
+/* _get_detect_clusters_single_threshold (roc_functions.py:356-383) for every utterance in one call:
+ * get_max_above_threshold (tsr_peaks, with l = T_n - C0 + 1) -> cluster_times (cluster_times.pyx:133-222,
+ * uint16 times, float32 C0/C1) -> get_cluster_starts_ends (roc_functions.py:189-210).  n_clusters i64 [N];
+ * utterance n's (start, end) pairs are stored from starts/ends[offsets[n]] on (i32 [offsets[N]] each).
+ * peak_counts i64 [N] / peak_times i32 [offsets[N]] optionally receive the peak lists (NULL to skip).
+ * Utterances must be shorter than 65535 scores (the reference's uint16 peak times); C0 a whole number. */
+int tsr_detect_clusters(tsr_ctx *ctx, const tsr_corpus *corpus, const float *vals, const int64_t *offsets, int64_t N,
+                        float threshold, float C0, float C1, int64_t *n_clusters, int32_t *starts, int32_t *ends,
+                        int64_t *peak_counts, int32_t *peak_times);
+/* cluster_times (cluster_times.pyx:133-222) for one utterance: times u16 [n] strictly increasing ->
+ * partition u8 [n + 1] (2 where a cluster starts and at the closing sentinel, 0 inside a cluster). */
+int tsr_cluster_times(tsr_ctx *ctx, const uint16_t *times, int64_t n, float C0, float C1, uint8_t *partition);
 /* get_max_detection_in_syllable_windows (roc_functions.py:88-139), the per-window part: window w is
  * the slice [starts[w], ends[w]) of row utt[w] of the zero-padded detection array (positions at or
  * beyond the utterance's T_n read 0, as in the reference's np.zeros rows; the caller clips ends to the

@@ -26,13 +26,16 @@ import tempfile
 
 REF_PKG = "/root/reference/template_speech_rec"
 MODULES = ["compute_likelihood_linear_filter", "code_parts", "spread_waliji_patches"]
+# compiled the same way, for the widenings of SURVEY 8(f): cluster_times.pyx (detection clustering, N2)
+EXTRA_MODULES = ["cluster_times"]
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "_ref")
 
 
-def built():
+def built(mods=None):
+    mods = MODULES + EXTRA_MODULES if mods is None else mods
     return all(any(f.startswith(m + ".") and f.endswith(".so") for f in os.listdir(OUT))
-               for m in MODULES) if os.path.isdir(OUT) else False
+               for m in mods) if os.path.isdir(OUT) else False
 
 
 def build(force=False):
@@ -52,7 +55,7 @@ def build(force=False):
                           include_dirs=[numpy.get_include()],
                           extra_compile_args=["-O2"],
                           define_macros=[("NPY_NO_DEPRECATED_API", "NPY_1_7_API_VERSION")])
-                for m in MODULES]
+                for m in MODULES + EXTRA_MODULES]
         # generated .c goes under tmp (the reference tree is read-only and no
         # reference text may land in this repository)
         exts = cythonize(exts, language_level="3str", force=True, quiet=True,
@@ -73,12 +76,24 @@ def build(force=False):
 
 def load():
     """Import the three compiled reference modules (or return None if absent)."""
-    if not built():
+    if not built(MODULES):
         return None
     import importlib
     sys.path.insert(0, OUT)
     try:
         return tuple(importlib.import_module(m) for m in MODULES)
+    finally:
+        sys.path.remove(OUT)
+
+
+def load_extra(name):
+    """Import one of EXTRA_MODULES (or None)."""
+    if not built([name]):
+        return None
+    import importlib
+    sys.path.insert(0, OUT)
+    try:
+        return importlib.import_module(name)
     finally:
         sys.path.remove(OUT)
 

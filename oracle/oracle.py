@@ -510,3 +510,35 @@ def mixture_e_step(data_mat, log_templates, log_invtemplates, weights):
     adj = np.exp(ll - mx[:, None]).sum(1)
     aff = np.exp(ll - (np.log(adj) + mx)[:, None])
     return float(np.log(adj).sum() + mx.sum()), aff / aff.sum(1, keepdims=True)
+
+
+# ---- detection clustering (second half).  cluster_times.pyx IS native code in the reference:
+# the C restatement above is pinned against the compiled module (oracle/_ref, golden g14).
+def cluster_times(times, C0, C1):
+    """cluster_times.pyx:133-222 -> partition uint8 [len(times) + 1]."""
+    t = _c(times, np.uint16)
+    out = np.empty(t.shape[0] + 1, np.uint8)
+    lib().tsr_oracle_cluster_times(_ptr(t), _i64(t.shape[0]), C.c_float(C0), C.c_float(C1), _ptr(out))
+    return out
+
+
+def get_cluster_starts_ends(potential_detect_times, cluster_partition):
+    """roc_functions.py:189-210."""
+    d, t, tuples = len(potential_detect_times), 0, []
+    while t < d:
+        start = potential_detect_times[t]
+        t += 1
+        while cluster_partition[t] != 2:
+            t += 1
+        tuples.append((start, potential_detect_times[t - 1] + 1))
+    return tuple(tuples)
+
+
+def get_detect_clusters_single_threshold(threshold, detection_array, detection_lengths, C0, C1, _cluster_times=None):
+    """roc_functions.py:356-383: per utterance, peaks above the threshold -> clustered (start, end) tuples."""
+    ct = _cluster_times or cluster_times
+    out = []
+    for vals, length in zip(detection_array, detection_lengths):
+        times = get_max_above_threshold(vals, int(length), threshold, C0)
+        out.append(get_cluster_starts_ends(times, ct(times, C0, C1)))
+    return tuple(out)

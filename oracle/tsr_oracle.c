@@ -287,3 +287,52 @@ TSR_EXPORT void tsr_oracle_score_corpus_u8(const uint8_t *feats, const int64_t *
                                  scores + foff[n], ids + foff[n], scratch);
     }
 }
+
+/* cluster_times.pyx:133-222 (cluster_times): partition of the ascending peak times of one utterance into
+ * clusters.  partition has n + 1 codes: 2 = a finished cluster starts here (and the closing sentinel),
+ * 0 = inside a cluster, 1 only transiently.  times are uint16, the running distances uint16 as in the
+ * reference (they wrap there too); C0 and C1 are float32 compared with the promoted integer differences. */
+TSR_EXPORT void tsr_oracle_cluster_times(const uint16_t *times, int64_t n64, float C0, float C1, uint8_t *part)
+{
+    const uint16_t n = (uint16_t)n64;
+    memset(part, 0, (size_t)n + 1);
+    part[0] = 1;
+    part[n] = 2;
+    for (uint16_t i = 1; i < n; ++i)
+        if ((float)((int)times[i] - (int)times[i - 1]) >= C0) part[i] = 1;
+    uint16_t start = 0, max_link = 0;
+    while (start < n) {
+        if (part[start + 1] > 0) {
+            part[start] = 2;
+            ++start;
+            while (part[start] != 1 && start < n) ++start;
+        } else {
+            uint16_t max_dist = 0, total = 0, k = 1;
+            while (part[start + k] == 0) {
+                const uint16_t cur = (uint16_t)(times[start + k] - times[start + k - 1]);
+                if (cur > max_dist) {
+                    max_link = (uint16_t)(start + k);
+                    max_dist = cur;
+                }
+                total = (uint16_t)(total + cur);
+                ++k;
+            }
+            if ((float)total > C1) {
+                if ((float)((int)times[start + k - 1] - (int)times[max_link]) <= C1)
+                    part[max_link] = 2;
+                else
+                    part[max_link] = 1;
+                if ((float)((int)times[max_link - 1] - (int)times[start]) <= C1) {
+                    part[start] = 2;
+                    if (part[max_link] == 1) start = max_link;
+                } else {
+                    part[start] = 1;
+                }
+            } else {
+                part[start] = 2;
+                start = (uint16_t)(start + k);
+                while (part[start] != 1 && start < n) ++start;
+            }
+        }
+    }
+}

@@ -357,3 +357,81 @@ int tsr_launch_mstep(tsr_ctx *ctx, const uint8_t *d_X, int64_t P, int D, int Dp,
     TSR_HIP(hipGetLastError());
     return TSR_OK;
 }
+
+// ---- detection clustering: cluster_times.pyx:133-222 + roc_functions.py:189-210 ----------
+// The reference's state machine over the ascending peak times of one utterance is inherently sequential and
+// tiny (a handful of peaks); one LANE per utterance runs it on the peak lists tsr_launch_peaks left on the
+// device, so that only the clustered (start, end) pairs go back to the host.  uint16 arithmetic for the
+// running distances as in the Cython source; part is scratch of n + 1 bytes per utterance.
+namespace {
+__global__ __launch_bounds__(64) void cluster_times_kernel(const int32_t *__restrict__ times_all, const int64_t *__restrict__ offsets,
+                                                           const int64_t *__restrict__ counts, int64_t N, float C0, float C1,
+                                                           uint8_t *__restrict__ part_all, int64_t *__restrict__ n_clusters,
+                                                           int32_t *__restrict__ starts, int32_t *__restrict__ ends)
+{
+    const int64_t u = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (u >= N) return;
+    const int32_t *times = times_all + offsets[u];
+    uint8_t *part = part_all + offsets[u] + u;  // n + 1 <= T_u + 1 bytes
+    const unsigned n = (unsigned)counts[u] & 0xffffu;
+    for (unsigned i = 0; i <= n; ++i) part[i] = 0;
+    part[0] = 1;
+    part[n] = 2;
+    for (unsigned i = 1; i < n; ++i)
+        if ((float)(times[i] - times[i - 1]) >= C0) part[i] = 1;
+    unsigned start = 0, max_link = 0;
+    while (start < n) {
+        if (part[start + 1] > 0) {
+            part[start] = 2;
+            ++start;
+            while (part[start] != 1 && start < n) ++start;
+        } else {
+            unsigned max_dist = 0, total = 0, k = 1;
+            while (part[start + k] == 0) {
+                const unsigned cur = (unsigned)(times[start + k] - times[start + k - 1]) & 0xffffu;
+                if (cur > max_dist) {
+                    max_link = start + k;
+                    max_dist = cur;
+                }
+                total = (total + cur) & 0xffffu;
+                ++k;
+            }
+            if ((float)total > C1) {
+                part[max_link] = ((float)(times[start + k - 1] - times[max_link]) <= C1) ? 2 : 1;
+                if ((float)(times[max_link - 1] - times[start]) <= C1) {
+                    part[start] = 2;
+                    if (part[max_link] == 1) start = max_link;
+                } else {
+                    part[start] = 1;
+                }
+            } else {
+                part[start] = 2;
+                start += k;
+                while (part[start] != 1 && start < n) ++start;
+            }
+        }
+    }
+    // get_cluster_starts_ends: (first time of the cluster, last time + 1)
+    int64_t nc = 0;
+    unsigned t = 0;
+    while (t < n) {
+        const int32_t s = times[t];
+        ++t;
+        while (part[t] != 2) ++t;
+        starts[offsets[u] + nc] = s;
+        ends[offsets[u] + nc] = times[t - 1] + 1;
+        ++nc;
+    }
+    n_clusters[u] = nc;
+}
+}  // namespace
+
+int tsr_launch_cluster_times(tsr_ctx *ctx, const int32_t *d_times, const int64_t *d_offsets, const int64_t *d_counts, int64_t N,
+                             float C0, float C1, uint8_t *d_part, int64_t *d_n_clusters, int32_t *d_starts, int32_t *d_ends)
+{
+    if (N <= 0) return TSR_OK;
+    hipLaunchKernelGGL(cluster_times_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, ctx->stream, d_times, d_offsets,
+                       d_counts, N, C0, C1, d_part, d_n_clusters, d_starts, d_ends);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}

@@ -738,6 +738,71 @@ TSR_API int tsr_peaks(tsr_ctx *ctx, const tsr_corpus *cp, const float *vals, con
     return TSR_OK;
 }
 
+// _get_detect_clusters_single_threshold (roc_functions.py:356-383) for every utterance: peaks above the
+// threshold (tsr_peaks), clustered by cluster_times.pyx:133-222, as (start, end) pairs.  peak_times may be
+// NULL; when given it also receives the peak lists (as tsr_peaks stores them) with their counts.
+TSR_API int tsr_detect_clusters(tsr_ctx *ctx, const tsr_corpus *cp, const float *vals, const int64_t *offsets, int64_t N,
+                                float threshold, float C0, float C1, int64_t *n_clusters, int32_t *starts, int32_t *ends,
+                                int64_t *peak_counts, int32_t *peak_times)
+{
+    TSR_REQUIRE(n_clusters && starts && ends, "tsr_detect_clusters: null output");
+    TSR_REQUIRE(C0 >= 1.0f && C0 == (float)(int)C0, "tsr_detect_clusters: C0 = %g must be a whole number >= 1 (it also bounds the peak search, roc_functions.py:178)", (double)C0);
+    const float *d_v;
+    const int64_t *d_off;
+    int64_t total;
+    TSR_TRY(peaks_source(ctx, cp, vals, offsets, N, &d_v, &d_off, &total, "tsr_detect_clusters"));
+    const int64_t n = cp ? cp->N : N;
+    const int64_t *offs = cp ? cp->offsets.data() : offsets;
+    if (n == 0) return TSR_OK;
+    for (int64_t i = 0; i < n; ++i)
+        TSR_REQUIRE(offs[i + 1] - offs[i] < 65535, "tsr_detect_clusters: utterance %lld has %lld scores; the reference keeps peak times in uint16", (long long)i, (long long)(offs[i + 1] - offs[i]));
+    void *dC = nullptr, *dT = nullptr, *dP = nullptr, *dR = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX2, (size_t)n * 16, &dC));
+    TSR_TRY(tsr_scratch(ctx, SLOT_W, (size_t)std::max<int64_t>(total, 1) * 4, &dT));
+    TSR_TRY(tsr_scratch(ctx, SLOT_RAW, (size_t)(total + n + 16), &dP));
+    TSR_TRY(tsr_scratch(ctx, SLOT_OUT, (size_t)std::max<int64_t>(total, 1) * 8, &dR));
+    int64_t *d_counts = (int64_t *)dC, *d_nc = d_counts + n;
+    int32_t *d_starts = (int32_t *)dR, *d_ends = d_starts + std::max<int64_t>(total, 1);
+    TSR_TRY(tsr_launch_peaks(ctx, d_v, d_off, n, threshold, (int)C0, d_counts, (int32_t *)dT));
+    TSR_TRY(tsr_launch_cluster_times(ctx, (const int32_t *)dT, d_off, d_counts, n, C0, C1, (uint8_t *)dP, d_nc, d_starts, d_ends));
+    TSR_HIP(hipMemcpyAsync(n_clusters, d_nc, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (peak_counts) TSR_HIP(hipMemcpyAsync(peak_counts, d_counts, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (total) {
+        TSR_TRY(tsr_download(ctx, starts, d_starts, (size_t)total * 4));
+        TSR_TRY(tsr_download(ctx, ends, d_ends, (size_t)total * 4));
+        if (peak_times) TSR_TRY(tsr_download(ctx, peak_times, dT, (size_t)total * 4));
+    }
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    return TSR_OK;
+}
+
+// cluster_times.pyx:133-222 for ONE list of ascending peak times: the partition codes (n + 1 bytes).
+TSR_API int tsr_cluster_times(tsr_ctx *ctx, const uint16_t *times, int64_t n, float C0, float C1, uint8_t *partition)
+{
+    TSR_REQUIRE(ctx && partition && (times || n == 0), "tsr_cluster_times: null pointer");
+    TSR_REQUIRE(n >= 0 && n < 65535, "tsr_cluster_times: %lld times (the reference counts them in uint16)", (long long)n);
+    for (int64_t i = 1; i < n; ++i)
+        TSR_REQUIRE(times[i] > times[i - 1], "tsr_cluster_times: times must be strictly increasing (index %lld)", (long long)i);
+    TSR_HIP(hipSetDevice(ctx->device));
+    std::vector<int32_t> t32((size_t)std::max<int64_t>(n, 1), 0);
+    for (int64_t i = 0; i < n; ++i) t32[(size_t)i] = times[i];
+    const int64_t offs[2] = {0, n}, cnt = n;
+    void *dT = nullptr, *dM = nullptr, *dP = nullptr, *dR = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_W, t32.size() * 4, &dT));
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX, 64, &dM));
+    TSR_TRY(tsr_scratch(ctx, SLOT_RAW, (size_t)n + 16, &dP));
+    TSR_TRY(tsr_scratch(ctx, SLOT_OUT, t32.size() * 8, &dR));
+    int64_t *d_off = (int64_t *)dM, *d_cnt = d_off + 2, *d_nc = d_off + 3;
+    TSR_HIP(hipMemcpyAsync(dT, t32.data(), t32.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(d_off, offs, 16, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(d_cnt, &cnt, 8, hipMemcpyHostToDevice, ctx->stream));
+    TSR_TRY(tsr_launch_cluster_times(ctx, (const int32_t *)dT, d_off, d_cnt, 1, C0, C1, (uint8_t *)dP, d_nc, (int32_t *)dR,
+                                     (int32_t *)dR + t32.size()));
+    TSR_HIP(hipMemcpyAsync(partition, dP, (size_t)n + 1, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    return TSR_OK;
+}
+
 TSR_API int tsr_window_peak_max(tsr_ctx *ctx, const tsr_corpus *cp, const float *vals, const int64_t *offsets,
                                 int64_t N, const int64_t *utt, const int64_t *starts, const int64_t *ends, int64_t W,
                                 float *out)

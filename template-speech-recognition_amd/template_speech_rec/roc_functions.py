@@ -3,9 +3,12 @@ right after the scoring path -- on the GPU:
 
     get_max_detection_in_syllable_windows   :88-139
     get_max_above_threshold                 :177-187
+    get_cluster_starts_ends / perform_detection_time_clustering   :189-221
+    _get_detect_clusters_single_threshold / get_detect_clusters_threshold_array   :356-398
 
-Everything downstream of them in the reference (clustering of the handful of peak times with
-cluster_times.pyx, ROC bookkeeping) works on a few integers per utterance and stays on the host.
+and the clustering of the peak times (cluster_times.pyx) behind them: one call turns a scored corpus
+into the clustered (start, end) detections of every utterance.  The ROC bookkeeping downstream stays
+on the host.
 """
 import numpy as np
 
@@ -56,3 +59,39 @@ def get_max_detection_in_syllable_windows(detection_array, example_start_end_tim
     if return_argsort_idx:
         return np.sort(max_detect_vals), np.argsort(max_detect_vals), utterance_ids
     return np.sort(max_detect_vals)
+
+
+def get_cluster_starts_ends(potential_detect_times, cluster_partition):
+    """:189-210 -- (first time, last time + 1) of every cluster of the partition."""
+    d, t, cluster_tuples = len(potential_detect_times), 0, []
+    while t < d:
+        cur_cluster_start = potential_detect_times[t]
+        t += 1
+        while cluster_partition[t] != 2:
+            t += 1
+        cluster_tuples.append((cur_cluster_start, potential_detect_times[t - 1] + 1))
+    return tuple(cluster_tuples)
+
+
+def perform_detection_time_clustering(potential_detect_times, C0, C1):
+    """:212-221 -- potential_detect_times: uint16, strictly increasing."""
+    from . import cluster_times
+    return get_cluster_starts_ends(potential_detect_times,
+                                   cluster_times.cluster_times(potential_detect_times, C0, C1))
+
+
+def _get_detect_clusters_single_threshold(threshold, detection_array, detection_lengths, C0, C1):
+    """:356-383 -- for every row of the detection array the clustered detections above the threshold, as a
+    tuple of (start, end) tuples; peaks and clusters of all utterances in one launch each."""
+    detection_array = np.asarray(detection_array, dtype=np.float32)
+    lengths = np.asarray(detection_lengths, dtype=np.int64)
+    offsets = np.concatenate(([0], np.cumsum(lengths)))
+    vals = np.concatenate([detection_array[n, :lengths[n]] for n in range(len(lengths))]) if len(lengths) \
+        else np.zeros(0, np.float32)
+    return api.detect_clusters(threshold, C0, C1, vals=vals, offsets=offsets)
+
+
+def get_detect_clusters_threshold_array(thresholds, detection_array, detection_lengths, C0, C1):
+    """:385-398."""
+    return tuple(_get_detect_clusters_single_threshold(threshold, detection_array, detection_lengths, C0, C1)
+                 if threshold > -np.inf else () for threshold in thresholds)

@@ -6,5 +6,5 @@ device-resident API they are built on.
 """
 from ._lib import (TSR_EXACT, TSR_FAST, TSR_W24, TSR_PARTS_AUTO, TSR_PARTS_VALU, TSR_PARTS_MFMA,  # noqa: F401
                    TsrError, LIB_PATH)
-from .api import (Bank, Context, Corpus, Parts, default_ctx, device_count, pack_filters, peaks,  # noqa: F401
-                  unique_id, window_peak_max)
+from .api import (Bank, Context, Corpus, Parts, default_ctx, detect_clusters, device_count,  # noqa: F401
+                  pack_filters, peaks, unique_id, window_peak_max)

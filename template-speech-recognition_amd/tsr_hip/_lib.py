@@ -48,6 +48,8 @@ SIGNATURES = {
     "tsr_classify_float_windows": [_p, _p, _p, _p, _p, _i64, _p, _p, _p],
     "tsr_corpus_classify_isolated": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p],
     "tsr_peaks": [_p, _p, _p, _p, _i64, _f, _int, _p, _p],
+    "tsr_detect_clusters": [_p, _p, _p, _p, _i64, _f, _f, _f, _p, _p, _p, _p, _p],
+    "tsr_cluster_times": [_p, _p, _i64, _f, _f, _p],
     "tsr_window_peak_max": [_p, _p, _p, _p, _i64, _p, _p, _p, _i64, _p],
     "tsr_edge_corpus_create": [_p, _p, _p, _i64, _i64, _int, _int, C.c_double, _p, _pp],
     "tsr_corpus_weighted_sums": [_p, _p, _p, _i64, _p],

@@ -330,6 +330,28 @@ def peaks(threshold, C0, corpus=None, vals=None, offsets=None, ctx=None):
     return [times[o[n]:o[n] + counts[n]].copy() for n in range(N)]
 
 
+def detect_clusters(threshold, C0, C1, corpus=None, vals=None, offsets=None, ctx=None, return_peaks=False):
+    """Per utterance the clustered detections above `threshold` (roc_functions.py:356-383 with
+    cluster_times.pyx:133-222) -> tuple over utterances of tuples of (start, end)."""
+    if corpus is not None:
+        c, h, v, o, N = corpus.ctx, corpus._h, None, corpus.offsets, corpus.N
+    else:
+        c = ctx or default_ctx()
+        v, o = _rows(vals, offsets)
+        h, N = None, len(o) - 1
+    nc = np.zeros(N, np.int64)
+    total = int(o[-1])
+    starts, ends = np.empty(total, np.int32), np.empty(total, np.int32)
+    pc = np.zeros(N, np.int64) if return_peaks else None
+    pt = np.empty(total, np.int32) if return_peaks else None
+    check(lib().tsr_detect_clusters(c._h, h, ptr(v), ptr(o), N, float(threshold), float(C0), float(C1), ptr(nc),
+                                    ptr(starts), ptr(ends), ptr(pc), ptr(pt)))
+    clusters = tuple(tuple((int(starts[o[n] + k]), int(ends[o[n] + k])) for k in range(int(nc[n]))) for n in range(N))
+    if return_peaks:
+        return clusters, [pt[o[n]:o[n] + pc[n]].copy() for n in range(N)]
+    return clusters
+
+
 def window_peak_max(utt, starts, ends, corpus=None, vals=None, offsets=None, ctx=None):
     """Per-window largest local maximum (roc_functions.py:107-116) -> f32 [W] (-inf where none)."""
     if corpus is not None:

@@ -713,3 +713,48 @@ def test_bernoulli_mixture_e_step_and_em(mods, oracle):
     ref._corpus = _HostSums()
     final_ref = ref.run_EM(1e-6, min_probability=0.05, max_iter=40, min_iter=5)
     assert abs(final - final_ref) <= 1e-4 * abs(final_ref)
+
+
+# ---- detection clustering (second half): pinned by the compiled cluster_times.pyx ------------
+def test_g14_cluster_times(mods):
+    import template_speech_rec.cluster_times as ct
+    g = golden("g14_cluster_times")
+    for i in range(int(g["n"])):
+        C0, C1 = (float(x) for x in g["C%d" % i])
+        got = ct.cluster_times(g["t%d" % i], C0, C1)
+        assert got.dtype == np.uint8 and np.array_equal(got, g["p%d" % i]), i
+    with pytest.raises(ValueError):
+        ct.cluster_times(np.array([3, 5], np.int32), 2, 9)               # the Cython buffer wants uint16
+    with pytest.raises(ValueError):
+        ct.cluster_times(np.array([5, 5], np.uint16), 2, 9)              # not strictly increasing
+
+
+def test_detect_clusters_chain(mods, oracle):
+    tsr_hip = mods[3]
+    import template_speech_rec.roc_functions as rf
+    from tsr_hip import synth
+    rng = np.random.default_rng(41)
+    lengths = np.array([300, 0, 45, 2, 180, 1, 97])
+    det = np.zeros((len(lengths), int(lengths.max()) + 2), np.float32)
+    for n, T in enumerate(lengths):
+        det[n, :T] = np.round(rng.normal(size=T) * 3) / 3
+    for thr, C0, C1 in ((-0.5, 8, 20), (0.0, 3, 5), (1.0, 20, 60), (-np.inf, 1, 1), (0.3, 33, 49)):
+        got = rf._get_detect_clusters_single_threshold(thr, det, lengths, C0, C1) if thr > -np.inf else \
+            tsr_hip.detect_clusters(thr, C0, C1, vals=np.concatenate([det[n, :lengths[n]] for n in range(len(lengths))]),
+                                    offsets=np.concatenate(([0], np.cumsum(lengths))))
+        want = oracle.get_detect_clusters_single_threshold(thr, det, lengths, C0, C1)
+        assert got == tuple(tuple((int(a), int(b)) for a, b in u) for u in want), (thr, C0, C1)
+    t = np.array([3, 5, 6, 20, 22, 40, 41, 42, 90], np.uint16)
+    assert rf.perform_detection_time_clustering(t, 4, 10) == oracle.get_cluster_starts_ends(t, oracle.cluster_times(t, 4, 10))
+    # straight from a scored corpus: nothing but the clusters leaves the device
+    c = synth.corpus(5, 30, 120, F=6, E=4, M=3, L=9)
+    corpus = tsr_hip.Corpus(c["feats"], c["offsets"])
+    corpus.score(tsr_hip.Bank(c["bank"]), tsr_hip.TSR_EXACT)
+    s, _ = corpus.download()
+    thr = float(np.quantile(s, 0.6))
+    got, peaks = tsr_hip.detect_clusters(thr, 9, 30, corpus=corpus, return_peaks=True)
+    rows = s.reshape(30, 120)
+    want = oracle.get_detect_clusters_single_threshold(thr, rows, [120] * 30, 9, 30)
+    assert got == tuple(tuple((int(a), int(b)) for a, b in u) for u in want)
+    for n in range(30):
+        assert np.array_equal(peaks[n], oracle.get_max_above_threshold(rows[n], 120, thr, 9))

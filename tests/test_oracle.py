@@ -206,3 +206,11 @@ def test_classification_restatement_matches_golden(oracle, isolated):
             oracle.compute_classification_E(E, None, flts, u, got[0], got[1], got[2], got[3], bank)
     for a, b in zip(got, want):
         assert np.array_equal(a, b)
+
+
+def test_g14_cluster_times(oracle):
+    """cluster_times.pyx is native code in the reference: g14 holds the compiled module's partitions."""
+    g = golden("g14_cluster_times")
+    for i in range(int(g["n"])):
+        C0, C1 = (float(x) for x in g["C%d" % i])
+        assert np.array_equal(oracle.cluster_times(g["t%d" % i], C0, C1), g["p%d" % i]), i

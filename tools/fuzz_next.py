@@ -60,6 +60,12 @@ for case in range(n_cases):
     if not np.array_equal(g, np.asarray(w, np.float32)):
         bad += 1
         print("case %d window peaks" % case)
+    C0c, C1c = int(rng.integers(1, 30)), int(rng.integers(1, 70))
+    gc = rf._get_detect_clusters_single_threshold(thr, det, lens, C0c, C1c)
+    wc = oracle.get_detect_clusters_single_threshold(thr, det, lens, C0c, C1c)
+    if gc != tuple(tuple((int(a), int(b)) for a, b in u) for u in wc):
+        bad += 1
+        print("case %d clusters lens=%s thr=%g C0=%d C1=%d" % (case, lens.tolist(), thr, C0c, C1c))
     # ---- edges ----
     H = int(rng.integers(1, 40))
     Ts = [int(x) for x in rng.integers(0, 120, size=int(rng.integers(1, 5)))]
