@@ -214,3 +214,19 @@ def test_g14_cluster_times(oracle):
     for i in range(int(g["n"])):
         C0, C1 = (float(x) for x in g["C%d" % i])
         assert np.array_equal(oracle.cluster_times(g["t%d" % i], C0, C1), g["p%d" % i]), i
+
+
+def test_cluster_times_restatement_vs_compiled_reference(oracle):
+    """When oracle/_ref holds the compiled cluster_times.pyx: the C restatement on fresh random peak lists."""
+    import build_ref
+    build_ref.build()
+    ct = build_ref.load_extra("cluster_times")
+    if ct is None:
+        pytest.skip("oracle/_ref/cluster_times not built here")
+    rng = np.random.default_rng(77)
+    for _ in range(500):
+        n = int(rng.integers(0, 40))
+        T = int(rng.integers(n + 2, 400))
+        times = np.sort(rng.choice(np.arange(1, T), size=n, replace=False)).astype(np.uint16)
+        C0, C1 = float(rng.integers(1, 40)), float(rng.integers(1, 80))
+        assert np.array_equal(oracle.cluster_times(times, C0, C1), ct.cluster_times(times, C0, C1))
