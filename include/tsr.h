@@ -145,6 +145,16 @@ int tsr_corpus_frames(const tsr_corpus *corpus, int64_t *total_frames);
 int tsr_code_parts(tsr_ctx *ctx, const uint8_t *X, int64_t X0, int64_t X1, int64_t E,
                    const double *log_parts, const double *log_invparts, int64_t K, int64_t P0,
                    int64_t P1, int threshold, int fast, double *out);
+/* code_parts_mag_aux (code_parts.pyx:138-242): code_parts on edges plus magnitude and auxiliary channels,
+ * a location being coded iff X_thresh_mask at the patch centre is set.  X_edges u8 [X0,X1,E], X_mags u8
+ * [X0,MD], X_aux u8 [X0,AD]; log tables f64: parts [K,P0,P1,E], mag [K,P0+MD], aux [K,P0*AD] (each with its
+ * "inv" twin); mask u8 [X0,X1] -> out f64 [X0-P0+1, X1-P1+1, K+1], the terms added in the reference's order
+ * (bit-identical map).  Integer divisions are the Python-2 / generated-C unsigned ones. */
+int tsr_code_parts_mag_aux(tsr_ctx *ctx, const uint8_t *X_edges, const uint8_t *X_mags, const uint8_t *X_aux,
+                           int64_t X0, int64_t X1, int64_t E, int64_t MD, int64_t AD, const double *log_parts,
+                           const double *log_invparts, const double *log_mag_parts, const double *log_mag_invparts,
+                           const double *log_aux_parts, const double *log_aux_invparts, int64_t K, int64_t P0,
+                           int64_t P1, const uint8_t *X_thresh_mask, double *out);
 /* spread_patches (code_parts.pyx:406-457) == spread_waliji_patches
  * (spread_waliji_patches.pyx:15-59).  X i64 [X0,X1] -> out u8 [X0,X1,K]. */
 int tsr_spread_patches(tsr_ctx *ctx, const int64_t *X, int64_t X0, int64_t X1, int r0, int r1,

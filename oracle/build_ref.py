@@ -28,14 +28,21 @@ REF_PKG = "/root/reference/template_speech_rec"
 MODULES = ["compute_likelihood_linear_filter", "code_parts", "spread_waliji_patches"]
 # compiled the same way, for the widenings of SURVEY 8(f): cluster_times.pyx (detection clustering, N2)
 EXTRA_MODULES = ["cluster_times"]
+# code_parts.pyx once more with language_level=2 into _ref/py2/: code_parts_mag_aux (:138-242) divides
+# unsigned ints with `/`, which is C integer division only under Python-2 semantics (N4)
+PY2_MODULES = ["code_parts"]
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "_ref")
 
 
-def built(mods=None):
+def built(mods=None, sub=""):
     mods = MODULES + EXTRA_MODULES if mods is None else mods
-    return all(any(f.startswith(m + ".") and f.endswith(".so") for f in os.listdir(OUT))
-               for m in mods) if os.path.isdir(OUT) else False
+    d = os.path.join(OUT, sub) if sub else OUT
+    ok = all(any(f.startswith(m + ".") and f.endswith(".so") for f in os.listdir(d))
+             for m in mods) if os.path.isdir(d) else False
+    if ok and mods is not None and not sub:
+        return ok
+    return ok and (sub != "" or built(PY2_MODULES, "py2"))
 
 
 def build(force=False):
@@ -69,6 +76,21 @@ def build(force=False):
         for f in os.listdir(cmd.build_lib):
             if f.endswith(".so"):
                 shutil.copy2(os.path.join(cmd.build_lib, f), os.path.join(OUT, f))
+        # the Python-2-semantics build
+        os.makedirs(os.path.join(OUT, "py2"), exist_ok=True)
+        exts2 = [Extension(m, [os.path.join(REF_PKG, m + ".pyx")], include_dirs=[numpy.get_include()],
+                           extra_compile_args=["-O2"],
+                           define_macros=[("NPY_NO_DEPRECATED_API", "NPY_1_7_API_VERSION")]) for m in PY2_MODULES]
+        exts2 = cythonize(exts2, language_level=2, force=True, quiet=True, build_dir=os.path.join(tmp, "cy2"))
+        dist2 = Distribution({"name": "tsr_ref_py2", "ext_modules": exts2})
+        cmd2 = dist2.get_command_obj("build_ext")
+        cmd2.build_lib = os.path.join(tmp, "lib2")
+        cmd2.build_temp = os.path.join(tmp, "obj2")
+        cmd2.ensure_finalized()
+        cmd2.run()
+        for f in os.listdir(cmd2.build_lib):
+            if f.endswith(".so"):
+                shutil.copy2(os.path.join(cmd2.build_lib, f), os.path.join(OUT, "py2", f))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return built()
@@ -86,16 +108,31 @@ def load():
         sys.path.remove(OUT)
 
 
-def load_extra(name):
-    """Import one of EXTRA_MODULES (or None)."""
-    if not built([name]):
+def load_extra(name, py2=False):
+    """Import one of EXTRA_MODULES, or (py2=True) the Python-2-semantics build of a module (or None)."""
+    sub = "py2" if py2 else ""
+    if not built([name], sub):
         return None
     import importlib
-    sys.path.insert(0, OUT)
+    import importlib.util
+    d = os.path.join(OUT, sub) if sub else OUT
+    if py2:  # same module name as the regular build: load by path under an alias
+        f = [x for x in os.listdir(d) if x.startswith(name + ".") and x.endswith(".so")][0]
+        spec = importlib.util.spec_from_file_location(name, os.path.join(d, f))
+        saved = sys.modules.pop(name, None)
+        try:
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+        finally:
+            sys.modules.pop(name, None)
+            if saved is not None:
+                sys.modules[name] = saved
+        return mod
+    sys.path.insert(0, d)
     try:
         return importlib.import_module(name)
     finally:
-        sys.path.remove(OUT)
+        sys.path.remove(d)
 
 
 if __name__ == "__main__":

@@ -542,3 +542,21 @@ def get_detect_clusters_single_threshold(threshold, detection_array, detection_l
         times = get_max_above_threshold(vals, int(length), threshold, C0)
         out.append(get_cluster_starts_ends(times, ct(times, C0, C1)))
     return tuple(out)
+
+
+def code_parts_mag_aux(X_edges, X_mags, X_aux, log_parts, log_invparts, log_mag_parts, log_mag_invparts,
+                       log_aux_parts, log_aux_invparts, X_thresh_mask):
+    """code_parts.pyx:138-242 (Python-2 integer division); pinned against the reference compiled with
+    language_level=2 (oracle/_ref/py2, golden g15)."""
+    Xe, Xm, Xa = _c(X_edges, np.uint8), _c(X_mags, np.uint8), _c(X_aux, np.uint8)
+    mk = _c(X_thresh_mask, np.uint8)
+    arrs = [_c(a, np.float64) for a in (log_parts, log_invparts, log_mag_parts, log_mag_invparts,
+                                        log_aux_parts, log_aux_invparts)]
+    K, P0, P1, E = arrs[0].shape
+    X0, X1 = Xe.shape[0], Xe.shape[1]
+    MD, AD = Xm.shape[1], Xa.shape[1]
+    assert arrs[2].shape == (K, P0 + MD) and arrs[4].shape == (K, P0 * AD) and mk.shape == (X0, X1)
+    out = np.empty((X0 - P0 + 1, X1 - P1 + 1, K + 1), np.float64)
+    lib().tsr_oracle_code_parts_mag_aux(_ptr(Xe), _ptr(Xm), _ptr(Xa), _i64(X0), _i64(X1), _i64(E), _i64(MD), _i64(AD),
+                                        *[_ptr(a) for a in arrs], _i64(K), _i64(P0), _i64(P1), _ptr(mk), _ptr(out))
+    return out

@@ -336,3 +336,53 @@ TSR_EXPORT void tsr_oracle_cluster_times(const uint16_t *times, int64_t n64, flo
         }
     }
 }
+
+/* code_parts.pyx:138-242 (code_parts_mag_aux) with the unsigned-int arithmetic of the generated C under
+ * Python-2 semantics (`/` on unsigned ints is integer division).  X_edges u8 [X0,X1,E], X_mags u8 [X0,MD],
+ * X_aux u8 [X0,AD], lp/lip f64 [K,P0,P1,E], lmp/lmip f64 [K,P0+MD], lap/laip f64 [K,P0*AD], mask u8 [X0,X1]
+ * -> out f64 [N0,N1,K+1].  Per coded location the terms are added per part in the order: for each patch
+ * row i: its AD auxiliary terms; for each patch column j its E edge terms, after the column j == P1/2 the
+ * MD "which magnitude channel" terms; then the row's "any magnitude in the band" term. */
+TSR_EXPORT void tsr_oracle_code_parts_mag_aux(const uint8_t *Xe, const uint8_t *Xm, const uint8_t *Xa, int64_t X0,
+                                              int64_t X1, int64_t E, int64_t MD, int64_t AD, const double *lp,
+                                              const double *lip, const double *lmp, const double *lmip,
+                                              const double *lap, const double *laip, int64_t K, int64_t P0,
+                                              int64_t P1, const uint8_t *mask, double *out)
+{
+    const int64_t N0 = X0 - P0 + 1, N1 = X1 - P1 + 1;
+    memset(out, 0, (size_t)(N0 * N1 * (K + 1)) * sizeof(double));
+    for (int64_t i0 = 0; i0 < N0; ++i0)
+        for (int64_t j0 = 0; j0 < N1; ++j0) {
+            double *o = out + (i0 * N1 + j0) * (K + 1);
+            if (!mask[(i0 + P0 / 2) * X1 + j0 + P1 / 2]) {
+                o[0] = 0.0;
+                continue;
+            }
+            o[0] = -INFINITY;
+            for (int64_t i = 0; i < P0; ++i) {
+                unsigned tmp_freq_mag = 0;
+                for (int64_t j = 0; j < AD; ++j) {
+                    const double *t = Xa[(i0 + i) * AD + j] ? lap : laip;
+                    for (int64_t k = 0; k < K; ++k) o[k + 1] += t[k * (P0 * AD) + i * AD + j];
+                }
+                for (int64_t j = 0; j < P1; ++j) {
+                    const unsigned c = (unsigned)(((unsigned)(j0 + j) * (unsigned)MD) / (unsigned)X1);
+                    if (Xm[(i0 + i) * MD + c]) tmp_freq_mag = 1;
+                    for (int64_t z = 0; z < E; ++z) {
+                        const double *t = Xe[((i0 + i) * X1 + j0 + j) * E + z] ? lp : lip;
+                        for (int64_t k = 0; k < K; ++k) o[k + 1] += t[((k * P0 + i) * P1 + j) * E + z];
+                    }
+                    if (j == P1 / 2)
+                        for (unsigned mi = 0; mi < (unsigned)MD; ++mi) {
+                            const unsigned d = c - mi;  /* wraps like the reference's unsigned ints */
+                            const double *t = (d * d > 1u) ? lmip : lmp;
+                            for (int64_t k = 0; k < K; ++k) o[k + 1] += t[k * (P0 + MD) + mi + P0];
+                        }
+                }
+                {
+                    const double *t = tmp_freq_mag ? lmp : lmip;
+                    for (int64_t k = 0; k < K; ++k) o[k + 1] += t[k * (P0 + MD) + i];
+                }
+            }
+        }
+}

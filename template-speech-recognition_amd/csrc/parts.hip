@@ -487,3 +487,78 @@ int tsr_launch_spread_stream(tsr_ctx *ctx, const int32_t *d_A, int64_t N1, int r
     TSR_HIP(hipGetLastError());
     return TSR_OK;
 }
+
+// ---- code_parts_mag_aux (code_parts.pyx:138-242) -------------------------------------------------------------
+// Edges + magnitude channels + auxiliary channels.  One lane per patch location, KC parts per pass; the
+// host lays the six tables out as ONE sequence of {inv, part} pairs in exactly the order in which the
+// reference adds its terms (per patch row: AD auxiliary terms, P1 x E edge terms with the MD channel terms
+// behind column P1/2, then the row's band term), so the kernel only has to produce the selector bit of
+// every term -- the data bit, the unsigned "(c - mag_i)^2 > 1" test, the row's tmp_freq_mag flag -- and add.
+// The unsigned arithmetic is the generated C's (Python-2 `/` on unsigned ints).
+namespace {
+constexpr int kMagKC = 8;
+__global__ __launch_bounds__(kThreads) void code_parts_mag_aux_kernel(
+    const uint8_t *__restrict__ Xe, const uint8_t *__restrict__ Xm, const uint8_t *__restrict__ Xa, int X0, int X1, int E,
+    int MD, int AD, int P0, int P1, const uint8_t *__restrict__ mask, const double *__restrict__ tab /*[term][K][2]*/, int K,
+    double *__restrict__ out)
+{
+    const int N0 = X0 - P0 + 1, N1 = X1 - P1 + 1;
+    const int64_t loc = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (loc >= (int64_t)N0 * N1) return;
+    const int i0 = (int)(loc / N1), j0 = (int)(loc - (int64_t)i0 * N1);
+    double *o = out + loc * (K + 1);
+    const bool coded = mask[(i0 + P0 / 2) * X1 + j0 + P1 / 2] != 0;
+    o[0] = coded ? -__builtin_inf() : 0.0;
+    if (!coded) {
+        for (int k = 0; k < K; ++k) o[k + 1] = 0.0;
+        return;
+    }
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 *t2 = reinterpret_cast<const d2 *>(tab);
+    for (int k0 = 0; k0 < K; k0 += kMagKC) {
+        double acc[kMagKC];
+#pragma unroll
+        for (int kk = 0; kk < kMagKC; ++kk) acc[kk] = 0.0;
+        int64_t term = 0;
+        auto add = [&](bool sel) {
+#pragma unroll
+            for (int kk = 0; kk < kMagKC; ++kk) {
+                const d2 tv = t2[term * K + min(k0 + kk, K - 1)];
+                acc[kk] += sel ? tv.y : tv.x;
+            }
+            ++term;
+        };
+        for (int i = 0; i < P0; ++i) {
+            unsigned tmp_freq_mag = 0;
+            for (int j = 0; j < AD; ++j) add(Xa[(i0 + i) * AD + j] != 0);
+            for (int j = 0; j < P1; ++j) {
+                const unsigned c = ((unsigned)(j0 + j) * (unsigned)MD) / (unsigned)X1;
+                if (Xm[(i0 + i) * MD + c]) tmp_freq_mag = 1;
+                for (int z = 0; z < E; ++z) add(Xe[((int64_t)(i0 + i) * X1 + j0 + j) * E + z] != 0);
+                if (j == P1 / 2)
+                    for (unsigned mi = 0; mi < (unsigned)MD; ++mi) {
+                        const unsigned d = c - mi;
+                        add(!(d * d > 1u));
+                    }
+            }
+            add(tmp_freq_mag != 0);
+        }
+#pragma unroll
+        for (int kk = 0; kk < kMagKC; ++kk)
+            if (k0 + kk < K) o[k0 + kk + 1] = acc[kk];
+    }
+}
+}  // namespace
+
+int tsr_launch_code_parts_mag_aux(tsr_ctx *ctx, const uint8_t *d_Xe, const uint8_t *d_Xm, const uint8_t *d_Xa, int64_t X0,
+                                  int64_t X1, int64_t E, int64_t MD, int64_t AD, int64_t P0, int64_t P1, const uint8_t *d_mask,
+                                  const double *d_tab, int64_t K, double *d_out)
+{
+    const int64_t n_loc = (X0 - P0 + 1) * (X1 - P1 + 1);
+    if (n_loc <= 0) return TSR_OK;
+    hipLaunchKernelGGL(code_parts_mag_aux_kernel, dim3((unsigned)((n_loc + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       ctx->stream, d_Xe, d_Xm, d_Xa, (int)X0, (int)X1, (int)E, (int)MD, (int)AD, (int)P0, (int)P1, d_mask, d_tab,
+                       (int)K, d_out);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}

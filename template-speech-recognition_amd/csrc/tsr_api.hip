@@ -1125,6 +1125,54 @@ TSR_API int tsr_code_parts(tsr_ctx *ctx, const uint8_t *X, int64_t X0, int64_t X
     return s;
 }
 
+// code_parts_mag_aux (code_parts.pyx:138-242): edges + magnitude + auxiliary channels, one-shot.
+TSR_API int tsr_code_parts_mag_aux(tsr_ctx *ctx, const uint8_t *X_edges, const uint8_t *X_mags, const uint8_t *X_aux,
+                                   int64_t X0, int64_t X1, int64_t E, int64_t MD, int64_t AD, const double *lp,
+                                   const double *lip, const double *lmp, const double *lmip, const double *lap,
+                                   const double *laip, int64_t K, int64_t P0, int64_t P1, const uint8_t *mask, double *out)
+{
+    TSR_REQUIRE(ctx && X_edges && X_mags && X_aux && lp && lip && lmp && lmip && lap && laip && mask && out,
+                "tsr_code_parts_mag_aux: null pointer");
+    TSR_REQUIRE(X0 >= P0 && X1 >= P1 && P0 >= 1 && P1 >= 1 && E >= 1 && K >= 1 && MD >= 1 && AD >= 0,
+                "tsr_code_parts_mag_aux: bad geometry (map %lldx%lld, patch %lldx%lld)", (long long)X0, (long long)X1, (long long)P0, (long long)P1);
+    TSR_REQUIRE(X0 * X1 * E < ((int64_t)1 << 31) && K <= 65535, "tsr_code_parts_mag_aux: map too large");
+    // the six tables as one sequence of {inv, part} pairs in the reference's order of addition
+    const int64_t n_terms = P0 * (AD + P1 * E + MD + 1);
+    std::vector<double> tab((size_t)(n_terms * K * 2));
+    int64_t term = 0;
+    auto put = [&](const double *part, const double *inv, int64_t stride, int64_t idx) {
+        for (int64_t k = 0; k < K; ++k) {
+            tab[(size_t)((term * K + k) * 2 + 0)] = inv[k * stride + idx];
+            tab[(size_t)((term * K + k) * 2 + 1)] = part[k * stride + idx];
+        }
+        ++term;
+    };
+    for (int64_t i = 0; i < P0; ++i) {
+        for (int64_t j = 0; j < AD; ++j) put(lap, laip, P0 * AD, i * AD + j);
+        for (int64_t j = 0; j < P1; ++j) {
+            for (int64_t z = 0; z < E; ++z) put(lp, lip, P0 * P1 * E, (i * P1 + j) * E + z);
+            if (j == P1 / 2)
+                for (int64_t mi = 0; mi < MD; ++mi) put(lmp, lmip, P0 + MD, mi + P0);
+        }
+        put(lmp, lmip, P0 + MD, i);
+    }
+    TSR_HIP(hipSetDevice(ctx->device));
+    const int64_t n_loc = (X0 - P0 + 1) * (X1 - P1 + 1);
+    const size_t be = (size_t)(X0 * X1 * E), bm = (size_t)(X0 * MD), ba = (size_t)(X0 * AD), bk = (size_t)(X0 * X1);
+    void *dX = nullptr, *dO = nullptr, *dT = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_IN, be + bm + ba + bk + 64, &dX));
+    TSR_TRY(tsr_scratch(ctx, SLOT_OUT, (size_t)(n_loc * (K + 1)) * 8, &dO));
+    TSR_TRY(tsr_scratch(ctx, SLOT_W, tab.size() * 8, &dT));
+    uint8_t *dXe = (uint8_t *)dX, *dXm = dXe + be, *dXa = dXm + bm, *dMk = dXa + ba;
+    TSR_HIP(hipMemcpyAsync(dXe, X_edges, be, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(dXm, X_mags, bm, hipMemcpyHostToDevice, ctx->stream));
+    if (ba) TSR_HIP(hipMemcpyAsync(dXa, X_aux, ba, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(dMk, mask, bk, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(dT, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    TSR_TRY(tsr_launch_code_parts_mag_aux(ctx, dXe, dXm, dXa, X0, X1, E, MD, AD, P0, P1, dMk, (const double *)dT, K, (double *)dO));
+    return tsr_download(ctx, out, dO, (size_t)(n_loc * (K + 1)) * 8);
+}
+
 static int upload_part_ids(tsr_ctx *ctx, const int64_t *X, int64_t n, int64_t K, void **dA)
 {
     std::vector<int32_t> a((size_t)n);

@@ -152,6 +152,9 @@ int tsr_launch_max_detect_examples(tsr_ctx *ctx, const uint8_t *d_F, int64_t N, 
                                    const int64_t *d_lengths, double *d_tmp, double *d_out);
 int tsr_launch_out_geometry(tsr_ctx *ctx, const int64_t *d_ooff, const int32_t *d_beg, const int32_t *d_n0, int64_t N,
                             int g0, int64_t P_out, int32_t *d_src_row, int32_t *d_src_lo, int32_t *d_src_hi);
+int tsr_launch_code_parts_mag_aux(tsr_ctx *ctx, const uint8_t *d_Xe, const uint8_t *d_Xm, const uint8_t *d_Xa, int64_t X0,
+                                  int64_t X1, int64_t E, int64_t MD, int64_t AD, int64_t P0, int64_t P1, const uint8_t *d_mask,
+                                  const double *d_tab, int64_t K, double *d_out);
 // classify.hip
 int tsr_launch_window_argmax(tsr_ctx *ctx, const float *d_all, int64_t stride, int M, const int64_t *d_starts,
                              const int64_t *d_ends, int64_t W, float *d_score, int64_t *d_loc, int32_t *d_tid);

@@ -46,6 +46,36 @@ def code_parts_fast(X, log_parts, log_invparts, threshold):
     return _code(X, log_parts, log_invparts, threshold, 1)
 
 
+def code_parts_mag_aux(X_edges, X_mags, X_aux, log_parts, log_invparts, log_mag_parts, log_mag_invparts,
+                       log_aux_parts, log_aux_invparts, X_thresh_mask):
+    """code_parts.pyx:138-242.  Edge patches plus magnitude and auxiliary channels; a location is coded
+    iff X_thresh_mask at the patch centre is set.  Returns float64 [S-P0+1, T-P1+1, K+1], bit-identical to
+    the reference compiled with Python-2 semantics (its `/` on unsigned ints is integer division)."""
+    Xe = buffer(X_edges, np.uint8, 3, "X_edges", "UINT_t")
+    Xm = buffer(X_mags, np.uint8, 2, "X_mags", "UINT_t")
+    Xa = buffer(X_aux, np.uint8, 2, "X_aux", "UINT_t")
+    lp = buffer(log_parts, np.float64, 4, "log_parts", "DTYPE_t")
+    lip = buffer(log_invparts, np.float64, 4, "log_invparts", "DTYPE_t")
+    lmp = buffer(log_mag_parts, np.float64, 2, "log_mag_parts", "DTYPE_t")
+    lmip = buffer(log_mag_invparts, np.float64, 2, "log_mag_invparts", "DTYPE_t")
+    lap = buffer(log_aux_parts, np.float64, 2, "log_aux_parts", "DTYPE_t")
+    laip = buffer(log_aux_invparts, np.float64, 2, "log_aux_invparts", "DTYPE_t")
+    mk = buffer(X_thresh_mask, np.uint8, 2, "X_thresh_mask", "UINT_t")
+    K, P0, P1, E = lp.shape
+    X0, X1 = Xe.shape[0], Xe.shape[1]
+    MD, AD = Xm.shape[1], Xa.shape[1]
+    if (lip.shape != lp.shape or Xe.shape[2] != E or Xm.shape[0] != X0 or Xa.shape[0] != X0 or mk.shape != (X0, X1)
+            or lmp.shape != (K, P0 + MD) or lmip.shape != lmp.shape or lap.shape != (K, P0 * AD) or laip.shape != lap.shape):
+        raise ValueError("code_parts_mag_aux: inconsistent shapes (the reference indexes out of bounds here)")
+    if X0 < P0 or X1 < P1:
+        raise ValueError("patch larger than the map")
+    out = np.empty((X0 - P0 + 1, X1 - P1 + 1, K + 1), np.float64)
+    _lib.check(_lib.lib().tsr_code_parts_mag_aux(default_ctx()._h, _lib.ptr(Xe), _lib.ptr(Xm), _lib.ptr(Xa), X0, X1, E, MD, AD,
+                                                 _lib.ptr(lp), _lib.ptr(lip), _lib.ptr(lmp), _lib.ptr(lmip), _lib.ptr(lap),
+                                                 _lib.ptr(laip), K, P0, P1, _lib.ptr(mk), _lib.ptr(out)))
+    return out
+
+
 def spread_patches(X, spread_0_dim, spread_1_dim, num_parts):
     """code_parts.pyx:406-457.  X int64 [S, T] of part ids (0 = none) ->
     uint8 [S, T, num_parts]; out[i, j, p-1] = 1 iff part p occurs within the clipped

@@ -42,6 +42,7 @@ SIGNATURES = {
     "tsr_corpus_download": [_p, _p, _p, _p],
     "tsr_corpus_frames": [_p, C.POINTER(_i64)],
     "tsr_code_parts": [_p, _p, _i64, _i64, _i64, _p, _p, _i64, _i64, _i64, _int, _int, _p],
+    "tsr_code_parts_mag_aux": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p],
     "tsr_spread_patches": [_p, _p, _i64, _i64, _int, _int, _i64, _p],
     "tsr_spread_graph_patches": [_p, _p, _i64, _i64, _i64, _p],
     "tsr_corpus_classify_windows": [_p, _p, _p, _p, _p, _i64, _int, _p, _p, _p],

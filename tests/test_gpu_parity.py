@@ -758,3 +758,30 @@ def test_detect_clusters_chain(mods, oracle):
     assert got == tuple(tuple((int(a), int(b)) for a, b in u) for u in want)
     for n in range(30):
         assert np.array_equal(peaks[n], oracle.get_max_above_threshold(rows[n], 120, thr, 9))
+
+
+# ---- code_parts_mag_aux: pinned by the reference compiled with Python-2 semantics -------------
+def test_g15_code_parts_mag_aux(mods, oracle):
+    cp = mods[1]
+    g = golden("g15_code_parts_mag_aux")
+    names = ("Xe", "Xm", "Xa", "lp", "lip", "lmp", "lmip", "lap", "laip", "mask")
+    for i in range(int(g["n"])):
+        args = tuple(g["c%d_%s" % (i, n)] for n in names)
+        out = cp.code_parts_mag_aux(*args)
+        assert out.dtype == np.float64 and np.array_equal(out, g["c%d_out" % i]), i
+    rng = np.random.default_rng(15)
+    for _ in range(25):                                              # random geometry against the oracle
+        P0, P1, E, K = int(rng.integers(1, 7)), int(rng.integers(1, 7)), int(rng.choice([1, 4, 8])), int(rng.integers(1, 20))
+        X0, X1, MD, AD = P0 + int(rng.integers(0, 20)), P1 + int(rng.integers(0, 20)), int(rng.integers(1, 6)), int(rng.integers(1, 5))
+        Xe = (rng.random((X0, X1, E)) < 0.3).astype(np.uint8)
+        Xm = (rng.random((X0, MD)) < 0.4).astype(np.uint8)
+        Xa = (rng.random((X0, AD)) < 0.5).astype(np.uint8)
+        lp = np.log(rng.uniform(.05, .95, (K, P0, P1, E)))
+        lmp = np.log(rng.uniform(.05, .95, (K, P0 + MD)))
+        lap = np.log(rng.uniform(.05, .95, (K, P0 * AD)))
+        lip, lmip, laip = (np.log(1 - np.exp(a)) for a in (lp, lmp, lap))
+        mask = (rng.random((X0, X1)) < 0.7).astype(np.uint8)
+        args = (Xe, Xm, Xa, lp, lip, lmp, lmip, lap, laip, mask)
+        assert np.array_equal(cp.code_parts_mag_aux(*args), oracle.code_parts_mag_aux(*args))
+    with pytest.raises(ValueError):
+        cp.code_parts_mag_aux(Xe, Xm, Xa, lp.astype(np.float32), lip, lmp, lmip, lap, laip, mask)

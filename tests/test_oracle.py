@@ -230,3 +230,15 @@ def test_cluster_times_restatement_vs_compiled_reference(oracle):
         times = np.sort(rng.choice(np.arange(1, T), size=n, replace=False)).astype(np.uint16)
         C0, C1 = float(rng.integers(1, 40)), float(rng.integers(1, 80))
         assert np.array_equal(oracle.cluster_times(times, C0, C1), ct.cluster_times(times, C0, C1))
+
+
+def _g15_case(g, i):
+    return tuple(g["c%d_%s" % (i, n)] for n in ("Xe", "Xm", "Xa", "lp", "lip", "lmp", "lmip", "lap", "laip", "mask")), g["c%d_out" % i]
+
+
+def test_g15_code_parts_mag_aux(oracle):
+    """g15: the reference's code_parts_mag_aux compiled with Python-2 semantics (oracle/_ref/py2)."""
+    g = golden("g15_code_parts_mag_aux")
+    for i in range(int(g["n"])):
+        args, want = _g15_case(g, i)
+        assert np.array_equal(oracle.code_parts_mag_aux(*args), want), i
