@@ -3,9 +3,6 @@
 // instantiations in detect_mfma_i0/i1/i2.hip.
 #include "detect_mfma_kernel.inc"
 
-#include "detect_toep.h"
-#include "detect_ws.h"
-
 namespace tsr_fast {
 #define TSR_FAST_EXTERN(N) extern template int launch<N>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
 TSR_FAST_EXTERN(1) TSR_FAST_EXTERN(2) TSR_FAST_EXTERN(3) TSR_FAST_EXTERN(4) TSR_FAST_EXTERN(5) TSR_FAST_EXTERN(6)
@@ -53,10 +50,6 @@ struct FastBank {
     int32_t *d_frag_ptr = nullptr, *d_frag_idx = nullptr;
     SlotMeta *d_slots = nullptr;
     int max_slots = 0;
-    // block-Toeplitz kernel (detect_toep.hip): two limbs, every template a multiple of 32 taps
-    i32x4 *d_Wt = nullptr;  // [phase][coltile][2 column halves][nkb64][2 limbs][64 lanes]
-    int nkb64 = 0;
-    size_t wt_phase = 0;
 };
 
 template <typename T>
@@ -78,7 +71,6 @@ static void fast_bank_free_one(tsr_bank *bank, int which)
     (void)hipSetDevice(bank->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(fb->d_Wl);
-    (void)hipFree(fb->d_Wt);
     (void)hipFree(fb->d_col_slot);
     (void)hipFree(fb->d_col_tau);
     (void)hipFree(fb->d_g_nslots);
@@ -229,38 +221,8 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int NL)
                         for (int e = 0; e < 16; ++e)
                             if (k0 + e < D) dst[e] = limbs[((size_t)l * C + c) * D + k0 + e];
                     }
-    // ---- the same limbs in the block-Toeplitz kernel's register order (16-column halves of a
-    //      32-column tile, K-blocks of 64 features); a K-phase's last block may reach into the next
-    //      phase's features: those get zero weights here ---------------------------------------
-    bool toep = NL == 2;
-    for (int m = 0; m < M; ++m) toep = toep && bank->L[m] % 32 == 0;
-    const int nkb64 = (NKB + 1) / 2;
-    const size_t wt_phase = (size_t)G * CT * 2 * nkb64 * 2 * 64;
-    std::vector<i32x4> Wt;
-    if (toep) {
-        Wt.resize(wt_phase * n_phase);
-        memset(Wt.data(), 0, Wt.size() * sizeof(i32x4));
-        for (int ph = 0; ph < n_phase; ++ph)
-            for (int64_t tile = 0; tile < (int64_t)G * CT; ++tile)
-                for (int c = 0; c < 2; ++c)
-                    for (int kb = 0; kb < nkb64; ++kb)
-                        for (int l = 0; l < 2; ++l)
-                            for (int lane = 0; lane < 64; ++lane) {
-                                const int64_t col = tile * 32 + c * 16 + (lane & 15);
-                                if (col >= C) continue;
-                                int8_t *dst = reinterpret_cast<int8_t *>(
-                                    &Wt[ph * wt_phase + ((((size_t)tile * 2 + c) * nkb64 + kb) * 2 + l) * 64 + lane]);
-                                const int64_t kl0 = (int64_t)kb * 64 + 16 * (lane >> 4);
-                                for (int e = 0; e < 16; ++e) {
-                                    const int64_t kl = kl0 + e, k = (int64_t)ph * NKB * 32 + kl;
-                                    if (kl < (int64_t)NKB * 32 && k < D) dst[e] = limbs[((size_t)l * C + col) * D + k];
-                                }
-                            }
-    }
     FastBank *fb = new FastBank;
     fb->NL = NL;
-    fb->nkb64 = nkb64;
-    fb->wt_phase = wt_phase;
     fb->NKB = NKB;
     fb->KS = KS;
     fb->CT = CT;
@@ -273,7 +235,6 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int NL)
     fb->wl_phase = wl_phase;
     bank->fast[NL - 2] = fb;
     int s = upload(ctx, &fb->d_Wl, Wl);
-    if (s == TSR_OK && toep) s = upload(ctx, &fb->d_Wt, Wt);
     if (s == TSR_OK) s = upload(ctx, &fb->d_col_slot, col_slot);
     if (s == TSR_OK) s = upload(ctx, &fb->d_col_tau, col_tau);
     if (s == TSR_OK) s = upload(ctx, &fb->d_g_nslots, g_nslots);
@@ -344,142 +305,6 @@ static int build_plan(tsr_ctx *ctx, tsr_corpus *cp, int nseg, int Lmax)
     return TSR_OK;
 }
 
-// Banks whose templates are all multiples of 32 taps (two limbs): the wave-specialised
-// block-Toeplitz kernel of detect_toep.hip.  Same plan, same ring semantics, same results.
-static int launch_toep(tsr_ctx *ctx, const tsr_bank *bank, const FastBank *fb, tsr_corpus *cp, float *d_scores,
-                       int32_t *d_ids, float *d_all)
-{
-    const int64_t P = cp->P;
-    const int Dp = cp->Dp;
-    const int k_span = fb->NKB * 32;                     // features of one K-phase
-    const int k_read = fb->nkb64 * 64;                   // features a worker's K-blocks read per row
-    int row_bytes = fb->n_phase == 1 ? Dp : k_span;
-    int SB = row_bytes;
-    if (((SB >> 4) & 1) == 0) SB += 16;
-    int tile_bytes = 32 * SB + std::max(0, k_read + 16 - SB);
-    tile_bytes = (tile_bytes + 1023) / 1024 * 1024;
-    // a frame's sums are complete once the workers have emitted the tile lagT further on; the
-    // helper finishes it two iterations later and runs kAhead tiles ahead of them with the DMA
-    const int lagT = (bank->Lmax + 15 + 31) / 32;
-    int ring = 32;
-    while (ring < 32 * (lagT + 6)) ring *= 2;
-    const size_t lds = (size_t)tsr_toep::kBuffers * tile_bytes + (size_t)kMaxSlots * sizeof(SlotMeta) + 64 +
-                       (size_t)(fb->max_slots + 1) * (ring + 33) * 4 + 16;
-    if (lds > 160 * 1024) return TSR_ERR_UNSUPPORTED;
-    int nseg = std::max(1, ctx->cus / fb->G);
-    nseg = (int)std::max<int64_t>(1, std::min<int64_t>(nseg, (P + 63) / 64));
-    TSR_TRY(build_plan(ctx, cp, nseg, bank->Lmax));
-    const bool fragments = fb->n_phase > 1 || fb->G > 1;
-    void *raw_frag = nullptr;
-    if (fragments) TSR_TRY(tsr_scratch(ctx, 0, (size_t)fb->n_frag * P * sizeof(float), &raw_frag));
-    const bool flat = (SB == Dp) && fb->n_phase == 1;
-    for (int ph = 0; ph < fb->n_phase; ++ph) {
-        tsr_toep::Args a;
-        memset(&a, 0, sizeof a);
-        a.X = cp->d_feats + (size_t)ph * k_span;
-        a.Dp = Dp;
-        a.SB = SB;
-        a.src_slots = row_bytes >> 4;
-        a.tile_bytes = tile_bytes;
-        a.G = fb->G;
-        a.CT = fb->CT;
-        a.nseg = nseg;
-        a.seg = cp->d_plan;
-        a.Wt = fb->d_Wt + (size_t)ph * fb->wt_phase;
-        a.col_slot = fb->d_col_slot;
-        a.col_tau = fb->d_col_tau;
-        a.slots = reinterpret_cast<const tsr_toep::SlotMeta *>(fb->d_slots + (size_t)ph * fb->G * kMaxSlots);
-        a.g_nslots = fb->d_g_nslots;
-        a.utt_end = cp->d_utt_end;
-        a.P = P;
-        a.ring = ring;
-        a.lagT = lagT;
-        if (fragments) {
-            a.raw_frag = (float *)raw_frag;
-        } else {
-            a.scores = d_scores;
-            a.ids = d_ids;
-            a.all = d_all;
-        }
-        TSR_TRY(tsr_toep::launch(ctx, a, fb->nkb64, flat, nseg * fb->G, lds));
-    }
-    if (fragments) {
-        hipLaunchKernelGGL(frag_epilogue_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const float *)raw_frag, P, bank->M, fb->d_frag_ptr, fb->d_frag_idx, bank->d_L, bank->d_cf,
-                           cp->d_utt_end, d_scores, d_ids, d_all);
-        TSR_HIP(hipGetLastError());
-    }
-    return TSR_OK;
-}
-
-// Two limbs: the wave-specialised kernel of detect_ws.hip.  Same limb fragments, plan, ring
-// semantics and results as the general kernel.
-static int launch_ws(tsr_ctx *ctx, const tsr_bank *bank, const FastBank *fb, tsr_corpus *cp, float *d_scores,
-                     int32_t *d_ids, float *d_all)
-{
-    const int64_t P = cp->P;
-    const int Dp = cp->Dp;
-    const int k_span = fb->NKB * 32;
-    int row_bytes = fb->n_phase == 1 ? Dp : k_span;
-    int SB = row_bytes;
-    if (((SB >> 4) & 1) == 0) SB += 16;
-    int tile_bytes = 32 * SB + std::max(0, k_span + 16 - SB);
-    tile_bytes = (tile_bytes + 1023) / 1024 * 1024;
-    // a frame is final once the workers have emitted the tile `lag` further on; the helper finishes
-    // it two iterations later while the workers may be three tiles ahead of that
-    const int lag = (bank->Lmax - 1 + 31) / 32;
-    int ring = 32;
-    while (ring < 32 * (lag + 6)) ring *= 2;
-    const size_t lds = (size_t)tsr_ws::kBuffers * tile_bytes + (size_t)kMaxSlots * sizeof(SlotMeta) + 64 +
-                       (size_t)(fb->max_slots + 1) * (ring + 33) * 4 + 16;
-    if (lds > 160 * 1024) return TSR_ERR_UNSUPPORTED;
-    int nseg = std::max(1, ctx->cus / fb->G);
-    nseg = (int)std::max<int64_t>(1, std::min<int64_t>(nseg, (P + 63) / 64));
-    TSR_TRY(build_plan(ctx, cp, nseg, bank->Lmax));
-    const bool fragments = fb->n_phase > 1 || fb->G > 1;
-    void *raw_frag = nullptr;
-    if (fragments) TSR_TRY(tsr_scratch(ctx, 0, (size_t)fb->n_frag * P * sizeof(float), &raw_frag));
-    const bool flat = (SB == Dp) && fb->n_phase == 1;
-    for (int ph = 0; ph < fb->n_phase; ++ph) {
-        tsr_ws::Args a;
-        memset(&a, 0, sizeof a);
-        a.X = cp->d_feats + (size_t)ph * k_span;
-        a.Dp = Dp;
-        a.SB = SB;
-        a.src_slots = row_bytes >> 4;
-        a.tile_bytes = tile_bytes;
-        a.G = fb->G;
-        a.CT = fb->CT;
-        a.nseg = nseg;
-        a.seg = cp->d_plan;
-        a.Wl = fb->d_Wl + (size_t)ph * fb->wl_phase;
-        a.col_slot = fb->d_col_slot;
-        a.col_tau = fb->d_col_tau;
-        a.slots = reinterpret_cast<const tsr_ws::SlotMeta *>(fb->d_slots + (size_t)ph * fb->G * kMaxSlots);
-        a.g_nslots = fb->d_g_nslots;
-        a.utt_end = cp->d_utt_end;
-        a.P = P;
-        a.ring = ring;
-        a.lag = lag;
-        a.lmax1 = bank->Lmax - 1;
-        if (fragments) {
-            a.raw_frag = (float *)raw_frag;
-        } else {
-            a.scores = d_scores;
-            a.ids = d_ids;
-            a.all = d_all;
-        }
-        TSR_TRY(tsr_ws::launch(ctx, a, fb->NKB, flat, nseg * fb->G, lds));
-    }
-    if (fragments) {
-        hipLaunchKernelGGL(frag_epilogue_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const float *)raw_frag, P, bank->M, fb->d_frag_ptr, fb->d_frag_idx, bank->d_L, bank->d_cf,
-                           cp->d_utt_end, d_scores, d_ids, d_all);
-        TSR_HIP(hipGetLastError());
-    }
-    return TSR_OK;
-}
-
 int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int flags,
                          float *d_scores, int32_t *d_ids, float *d_all)
 {
@@ -489,14 +314,6 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
     const int64_t P = cp->P;
     if (P == 0) return TSR_OK;
     const int Dp = cp->Dp;
-    if (fb->d_Wt && ctx->toep == 2) {
-        const int s = launch_toep(ctx, bank, fb, cp, d_scores, d_ids, d_all);
-        if (s != TSR_ERR_UNSUPPORTED) return s;  // (does not fit the LDS: the general kernel below)
-    }
-    if (NL == 2 && ctx->toep == 1) {
-        const int s = launch_ws(ctx, bank, fb, cp, d_scores, d_ids, d_all);
-        if (s != TSR_ERR_UNSUPPORTED) return s;  // (does not fit the LDS: the general kernel below)
-    }
     // LDS row: the bytes one pass needs of a frame (the whole resident row, or one K-phase of
     // it), as an odd number of 16-byte slots so that b128 fragment reads are conflict-free
     const int k_span = fb->KS * fb->NKB * 32;

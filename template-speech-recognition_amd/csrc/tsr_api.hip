@@ -76,7 +76,6 @@ TSR_API int tsr_ctx_create(int device, tsr_ctx **out)
     TSR_REQUIRE(ctx, "tsr_ctx_create: out of host memory");
     ctx->device = device;
     ctx->cus = prop.multiProcessorCount;
-    if (const char *e = getenv("TSR_TOEP")) ctx->toep = e[0] - '0';
     ctx->hbm_bytes = (int64_t)prop.totalGlobalMem;
     snprintf(ctx->name, sizeof ctx->name, "%s (%s)", prop.name, prop.gcnArchName);
     TSR_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));

@@ -56,7 +56,6 @@ struct tsr_ctx {
     tsr_devbuf pinned;      // page-locked host staging for large downloads (see tsr_download)
     void *comm = nullptr;   // ncclComm_t when tsr_dist_init has run
     int nranks = 1, rank = 0;
-    int toep = 0;           // experimental TSR_FAST kernels (env TSR_TOEP): 1 = wave-specialised, 2 = block-Toeplitz
 };
 
 int tsr_scratch(tsr_ctx *ctx, int slot, size_t bytes, void **out);
