@@ -183,11 +183,16 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N")
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this driver)
     allcores = cpu_allcores() if (args.extras and world == 1) else None   # forks: before any GPU call
     # (TSR_DEVICE pins every rank to one GPU: a rehearsal of the N > 1 control flow on a one-GPU box)
     ctx = tsr_hip.Context(int(os.environ.get("TSR_DEVICE", local_rank)))
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # launched by torch.distributed.run
+        # one node: the host control plane can stay on the loopback interface (a container's hostname
+        # may not resolve, which is what gloo would otherwise use to pick its interface)
+        if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         import torch.distributed as dist  # host control plane only (gloo, CPU tensors)
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
