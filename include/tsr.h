@@ -252,6 +252,19 @@ int tsr_detect_clusters(tsr_ctx *ctx, const tsr_corpus *corpus, const float *val
 /* cluster_times (cluster_times.pyx:133-222) for one utterance: times u16 [n] strictly increasing ->
  * partition u8 [n + 1] (2 where a cluster starts and at the closing sentinel, 0 inside a cluster). */
 int tsr_cluster_times(tsr_ctx *ctx, const uint16_t *times, int64_t n, float C0, float C1, uint8_t *partition);
+/* cluster_times_template_lengths (cluster_times.pyx:221-310): the same state machine with the thresholds of
+ * the detected templates -- a link opens a cluster when it is >= template_lengths[template_components[i-1]],
+ * a cluster is split when it is longer than 1.5 x the length of its first detection's template.
+ * template_components u16 [n] must index template_lengths u16 [n_lengths] (the reference does not check). */
+int tsr_cluster_times_template_lengths(tsr_ctx *ctx, const uint16_t *times, const uint16_t *template_lengths,
+                                       int64_t n_lengths, const uint16_t *template_components, int64_t n,
+                                       uint8_t *partition);
+/* cluster_times_variable_length (cluster_times.pyx:73-131).  The reference's split loop never changes the
+ * partition (split_cluster :47-70 re-marks the end of the cluster it is asked to split), so the result is the
+ * link partition: partition[i] = 1 where i == 0 or times[i] - times[i-1] >= detection_lengths[i-1], else 0.
+ * times, detection_lengths i32 [n] -> partition u8 [n]. */
+int tsr_cluster_times_variable_length(tsr_ctx *ctx, const int32_t *times, const int32_t *detection_lengths, int64_t n,
+                                      uint8_t *partition);
 /* get_max_detection_in_syllable_windows (roc_functions.py:88-139), the per-window part: window w is
  * the slice [starts[w], ends[w]) of row utt[w] of the zero-padded detection array (positions at or
  * beyond the utterance's T_n read 0, as in the reference's np.zeros rows; the caller clips ends to the

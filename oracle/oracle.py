@@ -522,6 +522,22 @@ def cluster_times(times, C0, C1):
     return out
 
 
+def cluster_times_template_lengths(times, template_lengths, template_components):
+    """cluster_times.pyx:221-310 -> partition uint8 [len(times) + 1]."""
+    t, tl, tc = _c(times, np.uint16), _c(template_lengths, np.uint16), _c(template_components, np.uint16)
+    out = np.empty(t.shape[0] + 1, np.uint8)
+    lib().tsr_oracle_cluster_times_template_lengths(_ptr(t), _ptr(tl), _ptr(tc), _i64(t.shape[0]), _ptr(out))
+    return out
+
+
+def cluster_times_variable_length(times, detection_lengths):
+    """cluster_times.pyx:73-131 -> partition uint8 [len(times)]."""
+    t, dl = _c(times, np.int32), _c(detection_lengths, np.int32)
+    out = np.empty(t.shape[0], np.uint8)
+    lib().tsr_oracle_cluster_times_variable_length(_ptr(t), _ptr(dl), _i64(t.shape[0]), _ptr(out))
+    return out
+
+
 def get_cluster_starts_ends(potential_detect_times, cluster_partition):
     """roc_functions.py:189-210."""
     d, t, tuples = len(potential_detect_times), 0, []

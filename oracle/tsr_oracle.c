@@ -337,6 +337,69 @@ TSR_EXPORT void tsr_oracle_cluster_times(const uint16_t *times, int64_t n64, flo
     }
 }
 
+/* cluster_times.pyx:221-310 (cluster_times_template_lengths): cluster_times with the thresholds taken from
+ * the detected template: a link opens a new cluster when it is at least as long as the template of the
+ * detection before it (C0), a cluster is split when it is longer than 1.5 x the template of its first detection
+ * (C1; `uint16 * 1.5` is a double in the generated C, every operand is exact in it).  times u16 [n] strictly
+ * increasing, comps u16 [n] < n_lengths, lengths u16 [n_lengths] -> part u8 [n + 1]. */
+TSR_EXPORT void tsr_oracle_cluster_times_template_lengths(const uint16_t *times, const uint16_t *lengths,
+                                                          const uint16_t *comps, int64_t n64, uint8_t *part)
+{
+    const uint16_t n = (uint16_t)n64;
+    memset(part, 0, (size_t)n + 1);
+    part[0] = 1;
+    part[n] = 2;
+    for (uint16_t i = 1; i < n; ++i)
+        if ((int)times[i] - (int)times[i - 1] >= (int)lengths[comps[i - 1]]) part[i] = 1;
+    uint16_t start = 0, max_link = 0;
+    while (start < n) {
+        if (part[start + 1] > 0) {
+            part[start] = 2;
+            ++start;
+            while (part[start] != 1 && start < n) ++start;
+        } else {
+            uint16_t max_dist = 0, total = 0, k = 1;
+            while (part[start + k] == 0) {
+                const uint16_t cur = (uint16_t)(times[start + k] - times[start + k - 1]);
+                if (cur > max_dist) {
+                    max_link = (uint16_t)(start + k);
+                    max_dist = cur;
+                }
+                total = (uint16_t)(total + cur);
+                ++k;
+            }
+            if ((double)total > lengths[comps[start]] * 1.5) {
+                if ((double)((int)times[start + k - 1] - (int)times[max_link]) <= lengths[comps[max_link]] * 1.5)
+                    part[max_link] = 2;
+                else
+                    part[max_link] = 1;
+                if ((double)((int)times[max_link - 1] - (int)times[start]) <= lengths[comps[start]] * 1.5) {
+                    part[start] = 2;
+                    if (part[max_link] == 1) start = max_link;
+                } else {
+                    part[start] = 1;
+                }
+            } else {
+                part[start] = 2;
+                start = (uint16_t)(start + k);
+                while (part[start] != 1 && start < n) ++start;
+            }
+        }
+    }
+}
+
+/* cluster_times.pyx:73-131 (cluster_times_variable_length).  The function marks a cluster start wherever the
+ * gap to the previous detection is at least that detection's length, and then runs a split loop that never
+ * changes anything: longest_cluster_detect_id (:18-45) only ever selects clusters that END at a marker, and
+ * split_cluster (:47-70) walks to exactly that marker and sets it again (its max_jump_loc is computed and never
+ * used).  What it returns is therefore the link partition below (verified against the compiled module).
+ * times, lengths i32 [n] -> part u8 [n]. */
+TSR_EXPORT void tsr_oracle_cluster_times_variable_length(const int32_t *times, const int32_t *lengths, int64_t n,
+                                                         uint8_t *part)
+{
+    for (int64_t i = 0; i < n; ++i) part[i] = (i == 0 || times[i] - times[i - 1] >= lengths[i - 1]) ? 1 : 0;
+}
+
 /* code_parts.pyx:138-242 (code_parts_mag_aux) with the unsigned-int arithmetic of the generated C under
  * Python-2 semantics (`/` on unsigned ints is integer division).  X_edges u8 [X0,X1,E], X_mags u8 [X0,MD],
  * X_aux u8 [X0,AD], lp/lip f64 [K,P0,P1,E], lmp/lmip f64 [K,P0+MD], lap/laip f64 [K,P0*AD], mask u8 [X0,X1]

@@ -358,27 +358,33 @@ int tsr_launch_mstep(tsr_ctx *ctx, const uint8_t *d_X, int64_t P, int D, int Dp,
     return TSR_OK;
 }
 
-// ---- detection clustering: cluster_times.pyx:133-222 + roc_functions.py:189-210 ----------
+// ---- detection clustering: cluster_times.pyx:133-222 / :221-310 + roc_functions.py:189-210 --
 // The reference's state machine over the ascending peak times of one utterance is inherently sequential and
 // tiny (a handful of peaks); one LANE per utterance runs it on the peak lists tsr_launch_peaks left on the
 // device, so that only the clustered (start, end) pairs go back to the host.  uint16 arithmetic for the
-// running distances as in the Cython source; part is scratch of n + 1 bytes per utterance.
+// running distances as in the Cython source; part is scratch of n + 1 bytes per utterance.  With `lens_all`
+// (the template length of every detection) the thresholds are cluster_times_template_lengths': a link opens a
+// cluster when it is >= the length of the detection before it, a cluster is split when it is longer than
+// 1.5 x the length of its first detection (all of these are exact in f32).
 namespace {
 __global__ __launch_bounds__(64) void cluster_times_kernel(const int32_t *__restrict__ times_all, const int64_t *__restrict__ offsets,
                                                            const int64_t *__restrict__ counts, int64_t N, float C0, float C1,
-                                                           uint8_t *__restrict__ part_all, int64_t *__restrict__ n_clusters,
+                                                           const int32_t *__restrict__ lens_all, uint8_t *__restrict__ part_all, int64_t *__restrict__ n_clusters,
                                                            int32_t *__restrict__ starts, int32_t *__restrict__ ends)
 {
     const int64_t u = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (u >= N) return;
     const int32_t *times = times_all + offsets[u];
+    const int32_t *lens = lens_all ? lens_all + offsets[u] : nullptr;
+    auto c0 = [&](unsigned i) { return lens ? (float)lens[i] : C0; };         // threshold of the link behind detection i
+    auto c1 = [&](unsigned i) { return lens ? 1.5f * (float)lens[i] : C1; };  // longest cluster starting at detection i
     uint8_t *part = part_all + offsets[u] + u;  // n + 1 <= T_u + 1 bytes
     const unsigned n = (unsigned)counts[u] & 0xffffu;
     for (unsigned i = 0; i <= n; ++i) part[i] = 0;
     part[0] = 1;
     part[n] = 2;
     for (unsigned i = 1; i < n; ++i)
-        if ((float)(times[i] - times[i - 1]) >= C0) part[i] = 1;
+        if ((float)(times[i] - times[i - 1]) >= c0(i - 1)) part[i] = 1;
     unsigned start = 0, max_link = 0;
     while (start < n) {
         if (part[start + 1] > 0) {
@@ -396,9 +402,9 @@ __global__ __launch_bounds__(64) void cluster_times_kernel(const int32_t *__rest
                 total = (total + cur) & 0xffffu;
                 ++k;
             }
-            if ((float)total > C1) {
-                part[max_link] = ((float)(times[start + k - 1] - times[max_link]) <= C1) ? 2 : 1;
-                if ((float)(times[max_link - 1] - times[start]) <= C1) {
+            if ((float)total > c1(start)) {
+                part[max_link] = ((float)(times[start + k - 1] - times[max_link]) <= c1(max_link)) ? 2 : 1;
+                if ((float)(times[max_link - 1] - times[start]) <= c1(start)) {
                     part[start] = 2;
                     if (part[max_link] == 1) start = max_link;
                 } else {
@@ -426,12 +432,35 @@ __global__ __launch_bounds__(64) void cluster_times_kernel(const int32_t *__rest
 }
 }  // namespace
 
+// cluster_times_variable_length (cluster_times.pyx:73-131): what its never-splitting split loop leaves behind
+// is the link partition -- a cluster starts wherever the gap to the previous detection is at least that
+// detection's length: longest_cluster_detect_id (:18-45) only selects clusters that end at a marker and
+// split_cluster (:47-70) sets exactly that marker again.  One thread per detection.
+namespace {
+__global__ __launch_bounds__(256) void link_partition_kernel(const int32_t *__restrict__ times, const int32_t *__restrict__ lengths,
+                                                             int64_t n, uint8_t *__restrict__ part)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) part[i] = (i == 0 || times[i] - times[i - 1] >= lengths[i - 1]) ? 1 : 0;
+}
+}  // namespace
+
+int tsr_launch_link_partition(tsr_ctx *ctx, const int32_t *d_times, const int32_t *d_lengths, int64_t n, uint8_t *d_part)
+{
+    if (n <= 0) return TSR_OK;
+    hipLaunchKernelGGL(link_partition_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_times, d_lengths,
+                       n, d_part);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+
 int tsr_launch_cluster_times(tsr_ctx *ctx, const int32_t *d_times, const int64_t *d_offsets, const int64_t *d_counts, int64_t N,
-                             float C0, float C1, uint8_t *d_part, int64_t *d_n_clusters, int32_t *d_starts, int32_t *d_ends)
+                             float C0, float C1, const int32_t *d_lens, uint8_t *d_part, int64_t *d_n_clusters,
+                             int32_t *d_starts, int32_t *d_ends)
 {
     if (N <= 0) return TSR_OK;
     hipLaunchKernelGGL(cluster_times_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, ctx->stream, d_times, d_offsets,
-                       d_counts, N, C0, C1, d_part, d_n_clusters, d_starts, d_ends);
+                       d_counts, N, C0, C1, d_lens, d_part, d_n_clusters, d_starts, d_ends);
     TSR_HIP(hipGetLastError());
     return TSR_OK;
 }

@@ -764,7 +764,7 @@ TSR_API int tsr_detect_clusters(tsr_ctx *ctx, const tsr_corpus *cp, const float 
     int64_t *d_counts = (int64_t *)dC, *d_nc = d_counts + n;
     int32_t *d_starts = (int32_t *)dR, *d_ends = d_starts + std::max<int64_t>(total, 1);
     TSR_TRY(tsr_launch_peaks(ctx, d_v, d_off, n, threshold, (int)C0, d_counts, (int32_t *)dT));
-    TSR_TRY(tsr_launch_cluster_times(ctx, (const int32_t *)dT, d_off, d_counts, n, C0, C1, (uint8_t *)dP, d_nc, d_starts, d_ends));
+    TSR_TRY(tsr_launch_cluster_times(ctx, (const int32_t *)dT, d_off, d_counts, n, C0, C1, nullptr, (uint8_t *)dP, d_nc, d_starts, d_ends));
     TSR_HIP(hipMemcpyAsync(n_clusters, d_nc, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (peak_counts) TSR_HIP(hipMemcpyAsync(peak_counts, d_counts, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (total) {
@@ -776,29 +776,81 @@ TSR_API int tsr_detect_clusters(tsr_ctx *ctx, const tsr_corpus *cp, const float 
     return TSR_OK;
 }
 
-// cluster_times.pyx:133-222 for ONE list of ascending peak times: the partition codes (n + 1 bytes).
-TSR_API int tsr_cluster_times(tsr_ctx *ctx, const uint16_t *times, int64_t n, float C0, float C1, uint8_t *partition)
+// One list of ascending peak times through cluster_times_kernel: the partition codes (n + 1 bytes).
+// lens32 (may be null): the template length of every detection (cluster_times_template_lengths).
+static int cluster_one_list(tsr_ctx *ctx, const uint16_t *times, const int32_t *lens32, int64_t n, float C0, float C1,
+                            uint8_t *partition, const char *who)
 {
-    TSR_REQUIRE(ctx && partition && (times || n == 0), "tsr_cluster_times: null pointer");
-    TSR_REQUIRE(n >= 0 && n < 65535, "tsr_cluster_times: %lld times (the reference counts them in uint16)", (long long)n);
+    TSR_REQUIRE(n >= 0 && n < 65535, "%s: %lld times (the reference counts them in uint16)", who, (long long)n);
     for (int64_t i = 1; i < n; ++i)
-        TSR_REQUIRE(times[i] > times[i - 1], "tsr_cluster_times: times must be strictly increasing (index %lld)", (long long)i);
+        TSR_REQUIRE(times[i] > times[i - 1], "%s: times must be strictly increasing (index %lld)", who, (long long)i);
     TSR_HIP(hipSetDevice(ctx->device));
-    std::vector<int32_t> t32((size_t)std::max<int64_t>(n, 1), 0);
+    const size_t m = (size_t)std::max<int64_t>(n, 1);
+    std::vector<int32_t> t32(2 * m, 0);  // times, then lengths
     for (int64_t i = 0; i < n; ++i) t32[(size_t)i] = times[i];
+    if (lens32)
+        for (int64_t i = 0; i < n; ++i) t32[m + (size_t)i] = lens32[i];
     const int64_t offs[2] = {0, n}, cnt = n;
     void *dT = nullptr, *dM = nullptr, *dP = nullptr, *dR = nullptr;
     TSR_TRY(tsr_scratch(ctx, SLOT_W, t32.size() * 4, &dT));
     TSR_TRY(tsr_scratch(ctx, SLOT_AUX, 64, &dM));
     TSR_TRY(tsr_scratch(ctx, SLOT_RAW, (size_t)n + 16, &dP));
-    TSR_TRY(tsr_scratch(ctx, SLOT_OUT, t32.size() * 8, &dR));
+    TSR_TRY(tsr_scratch(ctx, SLOT_OUT, m * 8, &dR));
     int64_t *d_off = (int64_t *)dM, *d_cnt = d_off + 2, *d_nc = d_off + 3;
     TSR_HIP(hipMemcpyAsync(dT, t32.data(), t32.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     TSR_HIP(hipMemcpyAsync(d_off, offs, 16, hipMemcpyHostToDevice, ctx->stream));
     TSR_HIP(hipMemcpyAsync(d_cnt, &cnt, 8, hipMemcpyHostToDevice, ctx->stream));
-    TSR_TRY(tsr_launch_cluster_times(ctx, (const int32_t *)dT, d_off, d_cnt, 1, C0, C1, (uint8_t *)dP, d_nc, (int32_t *)dR,
-                                     (int32_t *)dR + t32.size()));
+    TSR_TRY(tsr_launch_cluster_times(ctx, (const int32_t *)dT, d_off, d_cnt, 1, C0, C1,
+                                     lens32 ? (const int32_t *)dT + m : nullptr, (uint8_t *)dP, d_nc, (int32_t *)dR,
+                                     (int32_t *)dR + m));
     TSR_HIP(hipMemcpyAsync(partition, dP, (size_t)n + 1, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    return TSR_OK;
+}
+
+// cluster_times.pyx:133-222 for ONE list of ascending peak times.
+TSR_API int tsr_cluster_times(tsr_ctx *ctx, const uint16_t *times, int64_t n, float C0, float C1, uint8_t *partition)
+{
+    TSR_REQUIRE(ctx && partition && (times || n == 0), "tsr_cluster_times: null pointer");
+    return cluster_one_list(ctx, times, nullptr, n, C0, C1, partition, "tsr_cluster_times");
+}
+
+// cluster_times.pyx:221-310 (cluster_times_template_lengths) for ONE list of ascending peak times.
+TSR_API int tsr_cluster_times_template_lengths(tsr_ctx *ctx, const uint16_t *times, const uint16_t *template_lengths,
+                                               int64_t n_lengths, const uint16_t *template_components, int64_t n,
+                                               uint8_t *partition)
+{
+    TSR_REQUIRE(ctx && partition && ((times && template_components && template_lengths) || n == 0),
+                "tsr_cluster_times_template_lengths: null pointer");
+    TSR_REQUIRE(n >= 0 && n_lengths >= 0, "tsr_cluster_times_template_lengths: negative size");
+    std::vector<int32_t> lens((size_t)std::max<int64_t>(n, 1), 0);
+    for (int64_t i = 0; i < n; ++i) {
+        TSR_REQUIRE(template_components[i] < n_lengths,
+                    "tsr_cluster_times_template_lengths: template_components[%lld] = %d but only %lld template lengths "
+                    "(the reference reads out of bounds here)",
+                    (long long)i, (int)template_components[i], (long long)n_lengths);
+        lens[(size_t)i] = template_lengths[template_components[i]];
+    }
+    return cluster_one_list(ctx, times, lens.data(), n, 0.0f, 0.0f, partition, "tsr_cluster_times_template_lengths");
+}
+
+// cluster_times.pyx:73-131 (cluster_times_variable_length) for ONE list of detection times: partition u8 [n].
+TSR_API int tsr_cluster_times_variable_length(tsr_ctx *ctx, const int32_t *times, const int32_t *detection_lengths,
+                                              int64_t n, uint8_t *partition)
+{
+    TSR_REQUIRE(ctx && ((times && detection_lengths && partition) || n == 0),
+                "tsr_cluster_times_variable_length: null pointer");
+    TSR_REQUIRE(n >= 0, "tsr_cluster_times_variable_length: negative size");
+    if (n == 0) return TSR_OK;
+    TSR_HIP(hipSetDevice(ctx->device));
+    void *dT = nullptr, *dP = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_W, (size_t)n * 8, &dT));
+    TSR_TRY(tsr_scratch(ctx, SLOT_RAW, (size_t)n + 16, &dP));
+    int32_t *d_t = (int32_t *)dT, *d_l = d_t + n;
+    TSR_HIP(hipMemcpyAsync(d_t, times, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(d_l, detection_lengths, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    TSR_TRY(tsr_launch_link_partition(ctx, d_t, d_l, n, (uint8_t *)dP));
+    TSR_HIP(hipMemcpyAsync(partition, dP, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     TSR_HIP(hipStreamSynchronize(ctx->stream));
     return TSR_OK;
 }

@@ -169,8 +169,10 @@ int tsr_launch_window_peak_max(tsr_ctx *ctx, const float *d_v, const int64_t *d_
                                const int64_t *d_starts, const int64_t *d_ends, int64_t W, float *d_out);
 int tsr_launch_mstep(tsr_ctx *ctx, const uint8_t *d_X, int64_t P, int D, int Dp, const float *d_aff, int K,
                      float *d_part, int S, float *d_out);
+int tsr_launch_link_partition(tsr_ctx *ctx, const int32_t *d_times, const int32_t *d_lengths, int64_t n, uint8_t *d_part);
 int tsr_launch_cluster_times(tsr_ctx *ctx, const int32_t *d_times, const int64_t *d_offsets, const int64_t *d_counts, int64_t N,
-                             float C0, float C1, uint8_t *d_part, int64_t *d_n_clusters, int32_t *d_starts, int32_t *d_ends);
+                             float C0, float C1, const int32_t *d_lens, uint8_t *d_part, int64_t *d_n_clusters,
+                             int32_t *d_starts, int32_t *d_ends);
 // edges.hip
 int tsr_launch_edge_blocks(tsr_ctx *ctx, const double *d_S, const int64_t *d_utt_off, const int32_t *d_items,
                            int64_t n_items, int H, int block_length, int spread, double q, const double *abst,

@@ -51,6 +51,8 @@ SIGNATURES = {
     "tsr_peaks": [_p, _p, _p, _p, _i64, _f, _int, _p, _p],
     "tsr_detect_clusters": [_p, _p, _p, _p, _i64, _f, _f, _f, _p, _p, _p, _p, _p],
     "tsr_cluster_times": [_p, _p, _i64, _f, _f, _p],
+    "tsr_cluster_times_template_lengths": [_p, _p, _p, _i64, _p, _i64, _p],
+    "tsr_cluster_times_variable_length": [_p, _p, _p, _i64, _p],
     "tsr_window_peak_max": [_p, _p, _p, _p, _i64, _p, _p, _p, _i64, _p],
     "tsr_edge_corpus_create": [_p, _p, _p, _i64, _i64, _int, _int, C.c_double, _p, _pp],
     "tsr_corpus_weighted_sums": [_p, _p, _p, _i64, _p],

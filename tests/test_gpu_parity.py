@@ -729,6 +729,38 @@ def test_g14_cluster_times(mods):
         ct.cluster_times(np.array([5, 5], np.uint16), 2, 9)              # not strictly increasing
 
 
+def test_g16_cluster_times_template_lengths(mods, oracle):
+    import template_speech_rec.cluster_times as ct
+    g = golden("g16_cluster_times_template_lengths")
+    for i in range(int(g["n"])):
+        got = ct.cluster_times_template_lengths(g["t%d" % i], g["l%d" % i], g["c%d" % i])
+        assert got.dtype == np.uint8 and np.array_equal(got, g["p%d" % i]), i
+    rng = np.random.default_rng(161)
+    for _ in range(200):                                                     # fresh lists against the C restatement
+        n = int(rng.integers(0, 60))
+        times = np.sort(rng.choice(np.arange(1, n + 300), size=n, replace=False)).astype(np.uint16)
+        lengths = rng.integers(1, 70, size=int(rng.integers(1, 9))).astype(np.uint16)
+        comps = rng.integers(0, lengths.shape[0], size=n).astype(np.uint16)
+        assert np.array_equal(ct.cluster_times_template_lengths(times, lengths, comps),
+                              oracle.cluster_times_template_lengths(times, lengths, comps))
+    with pytest.raises(ValueError):                                          # component index past the lengths
+        ct.cluster_times_template_lengths(np.array([3, 9], np.uint16), np.array([4], np.uint16), np.array([0, 1], np.uint16))
+    with pytest.raises(ValueError):
+        ct.cluster_times_template_lengths(np.array([3, 9], np.uint16), np.array([4], np.uint16), np.array([0], np.uint16))
+
+
+def test_g17_cluster_times_variable_length(mods, oracle):
+    import template_speech_rec.cluster_times as ct
+    g = golden("g17_cluster_times_variable_length")
+    for i in range(int(g["n"])):
+        for dt in (np.int32, np.int64):
+            got = ct.cluster_times_variable_length(g["t%d" % i].astype(dt), g["l%d" % i].astype(dt))
+            assert got.dtype == np.uint8 and np.array_equal(got, g["p%d" % i]), i
+    assert ct.cluster_times_variable_length(np.zeros(0, np.int64), np.zeros(0, np.int64)).shape == (0,)
+    with pytest.raises(ValueError):
+        ct.cluster_times_variable_length(np.array([1, 4], np.uint16), np.array([2, 2], np.uint16))
+
+
 def test_detect_clusters_chain(mods, oracle):
     tsr_hip = mods[3]
     import template_speech_rec.roc_functions as rf

@@ -232,6 +232,38 @@ def test_cluster_times_restatement_vs_compiled_reference(oracle):
         assert np.array_equal(oracle.cluster_times(times, C0, C1), ct.cluster_times(times, C0, C1))
 
 
+def test_g16_cluster_times_template_lengths(oracle):
+    """cluster_times_template_lengths (cluster_times.pyx:221-310) as run by the compiled reference module."""
+    g = golden("g16_cluster_times_template_lengths")
+    for i in range(int(g["n"])):
+        got = oracle.cluster_times_template_lengths(g["t%d" % i], g["l%d" % i], g["c%d" % i])
+        assert np.array_equal(got, g["p%d" % i]), i
+
+
+def test_cluster_times_template_lengths_restatement_vs_compiled_reference(oracle):
+    import build_ref
+    build_ref.build()
+    ct = build_ref.load_extra("cluster_times")
+    if ct is None:
+        pytest.skip("oracle/_ref/cluster_times not built here")
+    rng = np.random.default_rng(78)
+    for _ in range(500):
+        n = int(rng.integers(0, 40))
+        T = int(rng.integers(n + 2, 400))
+        times = np.sort(rng.choice(np.arange(1, T), size=n, replace=False)).astype(np.uint16)
+        nl = int(rng.integers(1, 6))
+        lengths = rng.integers(1, 50, size=nl).astype(np.uint16)
+        comps = rng.integers(0, nl, size=n).astype(np.uint16)
+        assert np.array_equal(oracle.cluster_times_template_lengths(times, lengths, comps),
+                              ct.cluster_times_template_lengths(times, lengths, comps))
+
+
+def test_g17_cluster_times_variable_length(oracle):
+    g = golden("g17_cluster_times_variable_length")
+    for i in range(int(g["n"])):
+        assert np.array_equal(oracle.cluster_times_variable_length(g["t%d" % i], g["l%d" % i]), g["p%d" % i]), i
+
+
 def _g15_case(g, i):
     return tuple(g["c%d_%s" % (i, n)] for n in ("Xe", "Xm", "Xa", "lp", "lip", "lmp", "lmip", "lap", "laip", "mask")), g["c%d_out" % i]
 
