@@ -9,7 +9,6 @@ which agrees with the float64 value to ~1e-6 relative."""
 import numpy as np
 
 from . import compute_likelihood_linear_filter as cllf
-from .estimate_template import construct_linear_filter
 
 _filter_cache = {}
 

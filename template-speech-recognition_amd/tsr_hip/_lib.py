@@ -3,8 +3,6 @@ library or a gfx950 device is missing, calls raise."""
 import ctypes as C
 import os
 
-import numpy as np
-
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("TSR_HIP_LIB") or os.path.join(_PKG, "lib", "libtsr_hip.so")
 

@@ -11,7 +11,6 @@ import os
 
 import numpy as np
 
-from . import _lib
 from ._lib import TSR_EXACT, TSR_FAST, TSR_W24, check, lib, ptr
 
 _default_ctx = None
