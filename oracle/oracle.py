@@ -376,8 +376,8 @@ def compute_isolated_classification_E(E, phns, E_flts, utt_id, classify_array, c
 
 
 # ---- peak picking, restated from text: roc_functions.py is a Python-2 module with
-# no native part, so these two have no compiled reference behind them ("parity unpinned": the check is
-# HIP kernel vs this NumPy restatement only).
+# no native part.  The restatements are checked against the reference's own functions, executed where they lie
+# through oracle/py2ref.py (tests/test_reference_text.py); golden g19 holds that code's outputs.
 def get_max_above_threshold(detection_vals, detection_length, threshold, C0):
     """roc_functions.py:177-187."""
     l = detection_length - C0 + 1
@@ -405,7 +405,8 @@ def get_max_detection_in_syllable_windows(detection_array, example_start_end_tim
 
 
 # ---- edge front-end, restated from text: edge_signal_proc.py is a Python-2 module
-# without a native part ("parity unpinned": HIP kernel vs this NumPy restatement only).
+# without a native part.  Checked against the reference's own functions run through oracle/py2ref.py
+# (tests/test_reference_text.py: identical maps); golden g18 holds that code's outputs.
 EDGE_ORIENTATIONS = np.array([[0, 1], [0, -1], [1, 0], [-1, 0], [1, 1], [-1, -1], [-1, 1], [1, -1]])
 ABST_THRESHOLD = np.array([0.025, 0.025, 0.015, 0.015, 0.02, 0.02, 0.02, 0.02])
 

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Golden vectors from the reference's own PYTHON code (not a restatement): g18 = edge front-end
+(edge_signal_proc._edge_map_no_threshold + _edge_map_threshold_segments + reorg_part_for_fast_filtering,
+get_train_data.py:2547-2557), g19 = roc_functions.get_max_above_threshold /
+get_max_detection_in_syllable_windows / _get_detect_clusters_single_threshold over the compiled cluster_times.pyx.
+The Python-2 sources are executed where they lie through oracle/py2ref.py (lib2to3 + classic division + the
+boolean unary minus of the NumPy of that time).  Build container only:
+    python tests/golden/make_golden_reftext.py
+"""
+import itertools
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import build_ref  # noqa: E402
+import py2ref  # noqa: E402
+
+assert build_ref.build(), "oracle/_ref could not be built (no /root/reference?)"
+ABST = np.array([0.025, 0.025, 0.015, 0.015, 0.02, 0.02, 0.02, 0.02])
+
+esp = py2ref.load("edge_signal_proc", ["_edge_map_no_threshold", "_edge_map_threshold_segments"])
+gtd = py2ref.load("get_train_data", ["reorg_part_for_fast_filtering"])
+rng = np.random.default_rng(1800)
+d = {}
+cases = [(45, 200, 40, 1, .7), (20, 93, 40, 3, .7), (12, 57, 25, 0, .5), (5, 41, 41, 2, .9), (30, 64, 16, 1, .3), (9, 4, 4, 1, .7)]
+for i, (H, T, bl, sl, q) in enumerate(cases):
+    S = rng.standard_normal((H, T)) * (0.05 if i == 2 else 1.0)
+    if i in (1, 4):
+        S = np.round(S * 4) / 4                       # ties at the quantile
+    E, breaks, orient = esp["_edge_map_no_threshold"](S.copy())
+    esp["_edge_map_threshold_segments"](E, bl, sl, threshold=q, edge_orientations=orient.astype(int),
+                                        edge_feature_row_breaks=breaks.astype(int), abst_threshold=ABST)
+    d["S%d" % i], d["p%d" % i] = S, np.array([bl, sl, q])
+    d["out%d" % i] = np.asarray(gtd["reorg_part_for_fast_filtering"](E)).astype(np.uint8)
+d["n"] = np.int64(len(cases))
+path = os.path.join(HERE, "g18_edge_features_reftext.npz")
+np.savez_compressed(path, **d)
+print("g18_edge_features_reftext %.1f KB" % (os.path.getsize(path) / 1024))
+
+roc = py2ref.load("roc_functions", ["get_max_above_threshold", "get_max_detection_in_syllable_windows",
+                                    "_get_detect_clusters_single_threshold"],
+                  env={"itertools": itertools, "cluster_times": build_ref.load_extra("cluster_times")})
+rng = np.random.default_rng(1900)
+d = {}
+n_cases = 12
+for i in range(n_cases):
+    N, T = int(rng.integers(1, 6)), int(rng.integers(20, 160))
+    arr = rng.standard_normal((N, T)).astype(np.float32)
+    if i % 3 == 0:
+        arr = np.round(arr * 2) / 2
+    C0, C1 = int(rng.integers(2, 9)), int(rng.integers(3, 40))
+    lengths = rng.integers(C0 + 4, T + 1, size=N)
+    thr = float(rng.choice([-1.0, 0.0, 0.5, 1.5]))
+    clusters = roc["_get_detect_clusters_single_threshold"](thr, arr, lengths, C0, C1)
+    windows = [[(int(s), int(s) + int(rng.integers(1, 30))) for s in rng.integers(0, T, size=int(rng.integers(0, 4)))]
+               for _ in range(N)]
+    ws, we = -int(rng.integers(0, 10)), int(rng.integers(3, 25))
+    vals, order, utt = roc["get_max_detection_in_syllable_windows"](arr, windows, lengths, ws, we, return_argsort_idx=True)
+    d["a%d" % i], d["l%d" % i], d["p%d" % i] = arr, lengths, np.array([thr, C0, C1, ws, we])
+    for n in range(N):
+        d["pk%d_%d" % (i, n)] = roc["get_max_above_threshold"](arr[n], int(lengths[n]), thr, C0)
+        d["cl%d_%d" % (i, n)] = np.array(clusters[n], np.int64).reshape(-1, 2)
+        d["w%d_%d" % (i, n)] = np.array(windows[n], np.int64).reshape(-1, 2)
+    d["wv%d" % i], d["wo%d" % i], d["wu%d" % i] = vals, order, utt
+d["n"] = np.int64(n_cases)
+path = os.path.join(HERE, "g19_roc_functions_reftext.npz")
+np.savez_compressed(path, **d)
+print("g19_roc_functions_reftext %.1f KB" % (os.path.getsize(path) / 1024))

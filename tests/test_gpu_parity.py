@@ -761,6 +761,38 @@ def test_g17_cluster_times_variable_length(mods, oracle):
         ct.cluster_times_variable_length(np.array([1, 4], np.uint16), np.array([2, 2], np.uint16))
 
 
+def test_g18_edge_features_from_the_references_own_code(mods):
+    """g18: the reference's Python edge front-end itself (run through oracle/py2ref.py) -- not a restatement."""
+    import template_speech_rec.get_train_data as gtd
+    g = golden("g18_edge_features_reftext")
+
+    class P(object):
+        pass
+    for i in range(int(g["n"])):
+        par = P()
+        par.block_length, par.spread_length, par.threshold = int(g["p%d" % i][0]), int(g["p%d" % i][1]), float(g["p%d" % i][2])
+        got = gtd.get_edge_features(g["S%d" % i], par)
+        assert np.array_equal(got.astype(np.uint8), g["out%d" % i]), i
+
+
+def test_g19_roc_functions_from_the_references_own_code(mods):
+    """g19: roc_functions.py's own peak picking, window maxima and clustered detections (py2ref + compiled
+    cluster_times.pyx)."""
+    import template_speech_rec.roc_functions as rf
+    g = golden("g19_roc_functions_reftext")
+    for i in range(int(g["n"])):
+        arr, lengths = g["a%d" % i], g["l%d" % i]
+        thr, C0, C1, ws, we = (float(g["p%d" % i][0]),) + tuple(int(x) for x in g["p%d" % i][1:])
+        got = rf._get_detect_clusters_single_threshold(thr, arr, lengths, C0, C1)
+        windows = []
+        for n in range(arr.shape[0]):
+            assert np.array_equal(rf.get_max_above_threshold(arr[n], int(lengths[n]), thr, C0), g["pk%d_%d" % (i, n)])
+            assert np.array_equal(np.array(got[n], np.int64).reshape(-1, 2), g["cl%d_%d" % (i, n)]), (i, n)
+            windows.append([tuple(int(x) for x in w) for w in g["w%d_%d" % (i, n)]])
+        vals, order, utt = rf.get_max_detection_in_syllable_windows(arr, windows, lengths, ws, we, return_argsort_idx=True)
+        assert np.array_equal(vals, g["wv%d" % i].astype(np.float32)) and np.array_equal(utt, g["wu%d" % i])
+
+
 def test_detect_clusters_chain(mods, oracle):
     tsr_hip = mods[3]
     import template_speech_rec.roc_functions as rf
