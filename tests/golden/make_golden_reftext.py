@@ -70,3 +70,45 @@ d["n"] = np.int64(n_cases)
 path = os.path.join(HERE, "g19_roc_functions_reftext.npz")
 np.savez_compressed(path, **d)
 print("g19_roc_functions_reftext %.1f KB" % (os.path.getsize(path) / 1024))
+
+# g20: classification.Classifier (classification.py:26-149, template and collection types) as the reference runs it
+tt_f = py2ref.load("test_template", ["score_template_background_section"])
+
+
+class _NS(object):
+    pass
+tt = _NS()
+tt.score_template_background_section = tt_f["score_template_background_section"]
+pm = _NS()
+pm.TwoPartModel = type("TwoPartModel", (), {})
+cls = py2ref.load("classification", ["Classifier"], env={"tt": tt, "pm": pm})
+rng = np.random.default_rng(2000)
+d = {}
+n_cases = 6
+METHODS = ("score", "score_register", "score_no_bg", "coarse_score_like", "coarse_score_like_no_bg", "coarse_score_count")
+for i in range(n_cases):
+    D, L = int(rng.integers(6, 40)), int(rng.integers(6, 24)) * 2
+    bg = rng.uniform(.05, .4, size=D)
+    tmpl = rng.uniform(.02, .98, size=(D, L))
+    if i % 2:   # a collection; every other one with templates of different lengths (the coarse likelihoods of the
+        # reference assert equal lengths, so those cases record NaN for them)
+        cut = (2, 4) if i % 4 == 1 else (0, 0)
+        base = [tmpl, rng.uniform(.02, .98, size=(D, L - cut[0])), rng.uniform(.02, .98, size=(D, L - cut[1]))]
+    else:
+        base = tmpl
+    clf = cls["Classifier"](base, coarse_factor=2, bg=bg)
+    W = (rng.random((4, D, L)) < .3).astype(np.uint8)
+    d["bg%d" % i], d["W%d" % i], d["nt%d" % i] = bg, W, np.int64(len(base) if i % 2 else 0)
+    for k, t in enumerate(base if i % 2 else [base]):
+        d["t%d_%d" % (i, k)] = t
+    for m in METHODS:
+        try:
+            d["%s%d" % (m, i)] = np.array([float(getattr(clf, m)(w, bg) if m in ("score", "score_register", "coarse_score_like")
+                                                 else getattr(clf, m)(w)) for w in W])
+        except (AssertionError, IndexError):
+            d["%s%d" % (m, i)] = np.full(len(W), np.nan)
+    d["meta%d" % i] = np.array([clf.coarse_length, clf.window[0], clf.window[1]])
+d["n"] = np.int64(n_cases)
+path = os.path.join(HERE, "g20_classifier_reftext.npz")
+np.savez_compressed(path, **d)
+print("g20_classifier_reftext %.1f KB" % (os.path.getsize(path) / 1024))

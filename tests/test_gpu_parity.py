@@ -194,6 +194,28 @@ def test_g11_classifier_surface(mods, oracle):
     assert coll.coarse_length == L // 2 and clf.coarse_score_count(w) >= 0
 
 
+def test_g20_classifier_from_the_references_own_code(mods):
+    """g20: classification.Classifier (classification.py:26-149) itself, run through oracle/py2ref.py: every
+    scoring lambda of the template and collection types on random windows (f64 sums in the reference; the drop-in's
+    window scores come from the device in f32)."""
+    from template_speech_rec.classification import Classifier
+    g = golden("g20_classifier_reftext")
+    for i in range(int(g["n"])):
+        nt = int(g["nt%d" % i])
+        base = [g["t%d_%d" % (i, k)] for k in range(nt)] if nt else g["t%d_0" % i]
+        bg, W = g["bg%d" % i], g["W%d" % i]
+        clf = Classifier(base, coarse_factor=2, bg=bg)
+        assert [clf.coarse_length, clf.window[0], clf.window[1]] == [int(x) for x in g["meta%d" % i]]
+        for m in ("score", "score_register", "score_no_bg", "coarse_score_like", "coarse_score_like_no_bg",
+                  "coarse_score_count"):
+            want = g["%s%d" % (m, i)]
+            if np.isnan(want).any():          # the reference itself fails there (templates of different lengths)
+                continue
+            for w, x in zip(W, want):
+                got = getattr(clf, m)(w, bg) if m in ("score", "score_register", "coarse_score_like") else getattr(clf, m)(w)
+                assert abs(float(got) - x) <= 1e-5 * max(abs(x), 1.0), (i, m)
+
+
 # ---- seeded random parity against the oracle, both precision modes ---------------------
 def _check_bank(tsr_hip, oracle, corpus, flags, tol):
     bank = tsr_hip.Bank(corpus["bank"])
