@@ -496,8 +496,9 @@ def get_edge_features(S, block_length=40, spread_length=1, threshold=.7, abst_th
     return reorg_part_for_fast_filtering(E).astype(np.uint8)
 
 
-# ---- Bernoulli mixture E-step, restated from text in f64 ("parity unpinned": the
-# reference evaluates it with a float32 BLAS product whose summation order is not defined).
+# ---- Bernoulli mixture E-step, restated from text in f64 (the reference evaluates it with
+# a float32 BLAS product whose summation order is not defined: checks are tolerance-based; golden g21 holds what
+# the reference's own class computes, run through oracle/py2ref.py).
 def template_loglikelihoods(data_mat, log_templates, log_invtemplates):
     """bernoulli_mixture.py:287-291 in float64."""
     X = np.asarray(data_mat, np.float64)

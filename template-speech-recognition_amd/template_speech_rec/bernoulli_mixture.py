@@ -73,6 +73,18 @@ class BernoulliMixture:
         self.log_templates = np.log(self.templates)
         self.log_invtemplates = np.log(1 - self.templates)
 
+    def reset_templates(self):
+        """bernoulli_mixture.py:250-256: back to the flat [num_mix, data_length] tables (set_templates leaves them
+        in data shape, which the E-step does not take)."""
+        self.templates = self.work_templates.reshape(self.num_mix, self.data_length)
+        self.log_templates = np.log(self.templates)
+        self.log_invtemplates = np.log(1 - self.templates)
+
+    def init_templates(self):
+        """bernoulli_mixture.py:239-243."""
+        self.work_templates = np.zeros((self.num_mix, self.data_length))
+        self.templates = np.zeros((self.num_mix, self.data_length))
+
     def set_weights(self, new_weights):
         np.testing.assert_approx_equal(np.sum(new_weights), 1.)
         assert new_weights.shape == (self.num_mix,)

@@ -112,3 +112,35 @@ d["n"] = np.int64(n_cases)
 path = os.path.join(HERE, "g20_classifier_reftext.npz")
 np.savez_compressed(path, **d)
 print("g20_classifier_reftext %.1f KB" % (os.path.getsize(path) / 1024))
+
+# g21: bernoulli_mixture.BernoulliMixture (bernoulli_mixture.py:9-300) as the reference runs it: planted components,
+# init, first E-step, 12 EM iterations (fixed count: tol = 0 with max_iter = min_iter = 12)
+import contextlib  # noqa: E402
+import io  # noqa: E402
+import random  # noqa: E402
+
+bmc = py2ref.load("bernoulli_mixture", ["BernoulliMixture"], env={"random": random})
+rng = np.random.default_rng(2100)
+d = {}
+n_cases = 3
+for i in range(n_cases):
+    N, shape, K = int(rng.integers(150, 400)), (int(rng.integers(3, 7)), int(rng.integers(2, 6)), 8), int(rng.integers(2, 5))
+    protos = rng.uniform(0.05, 0.95, size=(K,) + shape)
+    data = (rng.random((N,) + shape) < protos[rng.integers(K, size=N)]).astype(np.uint8)
+    with contextlib.redirect_stdout(io.StringIO()):                    # (the class prints its progress)
+        mix = bmc["BernoulliMixture"](K, data, min_probability=0.05)
+        d["init_logt%d" % i] = np.asarray(mix.log_templates, np.float64)
+        d["tll%d" % i] = np.asarray(mix.get_template_loglikelihoods(), np.float64)
+        mix.hard_assignment = False                                       # (run_EM sets it; the E-step reads it)
+        ll0 = mix._compute_loglikelihoods()
+        d["aff0_%d" % i] = np.asarray(mix.affinities, np.float64)
+        mix.run_EM(0.0, min_probability=0.05, max_iter=12, min_iter=12)
+    d["data%d" % i], d["K%d" % i] = data, np.int64(K)
+    d["templates%d" % i], d["weights%d" % i] = np.asarray(mix.templates, np.float64), np.asarray(mix.weights, np.float64)
+    mix.reset_templates()                  # (run_EM leaves the log tables in data shape; the E-step wants them flat)
+    d["ll0_%d" % i], d["ll_%d" % i] = np.float64(ll0), np.float64(mix._compute_loglikelihoods())
+    d["iters%d" % i] = np.int64(mix.iterations)
+d["n"] = np.int64(n_cases)
+path = os.path.join(HERE, "g21_bernoulli_mixture_reftext.npz")
+np.savez_compressed(path, **d)
+print("g21_bernoulli_mixture_reftext %.1f KB" % (os.path.getsize(path) / 1024))

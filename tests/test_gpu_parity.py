@@ -737,6 +737,30 @@ def test_bernoulli_mixture_e_step_and_em(mods, oracle):
     assert abs(final - final_ref) <= 1e-4 * abs(final_ref)
 
 
+def test_g21_bernoulli_mixture_from_the_references_own_code(mods):
+    """g21: bernoulli_mixture.BernoulliMixture itself (run through oracle/py2ref.py): initialisation, template
+    log-likelihoods, first E-step and the state after 12 EM iterations.  The reference sums in a float32 BLAS
+    order that is not defined, so the comparison is tolerance-based."""
+    import template_speech_rec.bernoulli_mixture as bm
+    g = golden("g21_bernoulli_mixture_reftext")
+    for i in range(int(g["n"])):
+        data, K = g["data%d" % i], int(g["K%d" % i])
+        mix = bm.BernoulliMixture(K, data, min_probability=0.05)
+        assert np.allclose(mix.log_templates, g["init_logt%d" % i], rtol=1e-6, atol=1e-7)
+        tll, want = mix.get_template_loglikelihoods(), g["tll%d" % i]
+        assert np.max(np.abs(tll - want) / np.abs(want)) < 5e-6
+        ll0 = mix._compute_loglikelihoods()
+        assert abs(ll0 - float(g["ll0_%d" % i])) <= 1e-5 * abs(float(g["ll0_%d" % i]))
+        assert np.max(np.abs(mix.affinities - g["aff0_%d" % i])) < 2e-3
+        mix.run_EM(0.0, min_probability=0.05, max_iter=12, min_iter=12)
+        assert mix.iterations == int(g["iters%d" % i]) == 12
+        assert np.max(np.abs(mix.weights - g["weights%d" % i])) < 2e-3
+        assert np.max(np.abs(mix.templates - g["templates%d" % i])) < 5e-3
+        mix.reset_templates()
+        ll = mix._compute_loglikelihoods()
+        assert abs(ll - float(g["ll_%d" % i])) <= 1e-4 * abs(float(g["ll_%d" % i]))
+
+
 # ---- detection clustering (SURVEY 8(f) N2, second half): pinned by the compiled cluster_times.pyx ------------
 def test_g14_cluster_times(mods):
     import template_speech_rec.cluster_times as ct
