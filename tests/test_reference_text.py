@@ -233,3 +233,50 @@ def test_waliji_feature_map_restatement_is_the_references_code(oracle, ref_modul
         want = gtd["get_waliji_feature_map"](None, np.log(P), np.log(1 - P))
         got = oracle.waliji_feature_map(oracle.get_edge_features(S, 40, 1, .7), np.log(P), np.log(1 - P))
         assert np.array_equal(want, got), case
+
+
+def test_dropin_host_logic_is_the_references_code():
+    """The host-side NumPy helpers of the PRODUCT package (no GPU involved) against the reference's own functions."""
+    sys.path.insert(0, os.path.join(ROOT, "template-speech-recognition_amd"))
+    import template_speech_rec.classification as cl
+    import template_speech_rec.estimate_template as et
+    import template_speech_rec.get_train_data as gtd
+    import template_speech_rec.roc_functions as rf
+    r_gtd = py2ref.load("get_train_data", ["reorg_part_for_fast_filtering", "reorg_parts_for_fast_filtering",
+                                           "collapse_to_grid", "get_classify_windows"])
+    r_et = py2ref.load("estimate_template", ["construct_linear_filters", "construct_linear_filter"])
+    r_cl = py2ref.load("classification", ["map_coarse_frame_to_range", "get_coarse_segment", "_stretch_template"])
+    r_rf = py2ref.load("roc_functions", ["get_cluster_starts_ends"])
+    rng = np.random.default_rng(1808)
+    for case in range(25):
+        H, T, K = int(rng.integers(2, 20)), int(rng.integers(3, 60)), int(rng.integers(1, 6))
+        part = rng.random((8 * H, T))
+        assert np.array_equal(gtd.reorg_part_for_fast_filtering(part), r_gtd["reorg_part_for_fast_filtering"](part))
+        parts = rng.uniform(0, 1, size=(K, 8 * H, T))
+        assert np.array_equal(gtd.reorg_parts_for_fast_filtering(parts), r_gtd["reorg_parts_for_fast_filtering"](parts))
+        coded = rng.integers(0, 2, size=(T, H, K))
+        g0, g1 = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+        assert np.array_equal(gtd.collapse_to_grid(coded, g0, g1), r_gtd["collapse_to_grid"](coded, g0, g1))
+        flts = np.concatenate(([0], np.cumsum(rng.integers(3, 40, size=int(rng.integers(2, 9)))))).astype(np.int64)
+        for a, b in zip(gtd.get_classify_windows(None, flts), r_gtd["get_classify_windows"](None, flts)):
+            assert a.dtype == b.dtype and np.array_equal(a, b)
+        L, F, E = int(rng.integers(2, 20)), int(rng.integers(2, 9)), int(rng.integers(1, 9))
+        Ts = tuple(rng.uniform(0, 1, size=(L + i, F, E)) for i in range(2))
+        bgd = rng.uniform(0, .6, size=(F, E))
+        for all_cs in (False, True):
+            for (w0, c0), (w1, c1) in zip(et.construct_linear_filters(Ts, bgd, all_cs=all_cs),
+                                          r_et["construct_linear_filters"](Ts, bgd, all_cs=all_cs)):
+                assert w0.dtype == w1.dtype == np.float32 and np.array_equal(w0, w1) and np.array_equal(c0, c1)
+        seg = rng.random((F, T))
+        for ctype in ("max", "avg"):
+            for cf in (2, 3):
+                assert np.array_equal(cl.get_coarse_segment(seg, coarse_type=ctype, coarse_factor=cf),
+                                      r_cl["get_coarse_segment"](seg, coarse_type=ctype, coarse_factor=cf))
+        for tl in (max(2, T // 2), T, T + 7):
+            assert np.array_equal(cl._stretch_template(seg, F, tl), r_cl["_stretch_template"](seg, F, tl))
+        n = int(rng.integers(1, 12))
+        times = np.sort(rng.choice(np.arange(1, 300), size=n, replace=False)).astype(np.uint16)
+        part = np.zeros(n + 1, np.uint8)
+        part[0] = part[n] = 2
+        part[1:n][rng.random(n - 1) < .4] = 2
+        assert rf.get_cluster_starts_ends(times, part) == r_rf["get_cluster_starts_ends"](times, part)
