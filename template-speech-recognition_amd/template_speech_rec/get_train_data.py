@@ -82,20 +82,53 @@ def get_waliji_feature_map_from_edges(E2, log_part_blocks, log_invpart_blocks):
                           grid=(parts.P0, parts.P1), fast=True)
 
 
-def _compute_detection_E(E, detection_array, detection_template_ids, detect_lengths,
-                         linear_filters_cs, flags=api.TSR_EXACT, bank=None):
-    """Score one utterance against the bank and append the result as the next row
-    of detection_array / detection_template_ids, as :962-1011 does.  The phone-label
-    bookkeeping of the reference (example start/end times) is the caller's."""
-    E = np.asarray(E).astype(np.uint8)
+def phns_syllable_matches(phns, syllable):
+    """:66-70: indices where the phone sequence `syllable` starts in `phns`."""
+    syllable_len = len(syllable)
+    return np.array([phn_id for phn_id in range(len(phns) - syllable_len + 1)
+                     if np.all(phns[phn_id:phn_id + syllable_len] == np.array(syllable))])
+
+
+def map_array_to_coarse_coordinates(xs, coarsen_factor):
+    """:83-85."""
+    return ((xs + coarsen_factor / 2.) / coarsen_factor).astype(int)
+
+
+def get_examples_from_phns_ftls(syllable, phns, flts, log_part_blocks, coarse_length, verbose=False, phn_mapping=None):
+    """:87-131: (starts, ends) of the occurrences of `syllable`, or (None, None)."""
+    phn_matches = phns_syllable_matches(phns, syllable)
+    if phn_matches.shape[0] == 0:
+        return None, None
+    syllable_starts = flts[phn_matches]
+    syllable_ends = flts[phn_matches + len(syllable)]
+    if log_part_blocks is not None:
+        coarse_factor = log_part_blocks.shape[1]
+        syllable_starts = map_array_to_coarse_coordinates(syllable_starts, coarse_factor)
+        syllable_ends = np.clip(map_array_to_coarse_coordinates(syllable_ends, coarse_factor),
+                                syllable_starts + 1, coarse_length)
+    return syllable_starts, syllable_ends
+
+
+def _compute_detection_E(E, phns, E_flts, detection_array, detection_template_ids, detect_lengths,
+                         linear_filters_cs, syllable, example_start_end_times, phn_mapping=None, verbose=False,
+                         flags=api.TSR_EXACT, bank=None):
+    """:927-1012 with the reference's signature: score one utterance against the bank into the next row of
+    detection_array / detection_template_ids (row = len(detect_lengths)), append the (start, end) times of the
+    occurrences of `syllable` to example_start_end_times and the detect length to detect_lengths (0 for a
+    single-filter bank, as the reference leaves it).  `flags` / `bank` (a prepared tsr_hip.Bank) are extensions."""
+    example_starts, example_ends = get_examples_from_phns_ftls(syllable, phns, E_flts, None, E.shape[0], verbose=verbose)
+    E8 = np.asarray(E).astype(np.uint8)
     bank = bank or api.Bank(linear_filters_cs)
-    scores, ids = bank.score(E, flags=flags)
+    scores, ids = bank.score(E8, flags=flags)
     row = len(detect_lengths)
     detection_array[row, :E.shape[0]] = scores
-    if detection_template_ids is not None:
+    if detection_template_ids is not None and len(linear_filters_cs) > 1:
         detection_template_ids[row, :E.shape[0]] = ids
+    if example_starts is not None:
+        example_start_end_times.append(list(zip(example_starts, example_ends)))
+    else:
+        example_start_end_times.append([])
     detect_lengths.append(E.shape[0] if len(linear_filters_cs) > 1 else 0)
-    return scores, ids
 
 
 def get_detection_scores(utterances, linear_filters_cs, P_config=None, flags=api.TSR_EXACT, ctx=None):

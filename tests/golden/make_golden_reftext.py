@@ -144,3 +144,38 @@ d["n"] = np.int64(n_cases)
 path = os.path.join(HERE, "g21_bernoulli_mixture_reftext.npz")
 np.savez_compressed(path, **d)
 print("g21_bernoulli_mixture_reftext %.1f KB" % (os.path.getsize(path) / 1024))
+
+# g22: get_train_data._compute_detection_E (:927-1012) with its own signature, over the compiled detect: a few
+# utterances appended one after the other (rows, template ids, example times, detect lengths)
+cllf, _, _ = build_ref.load()
+gtd2 = py2ref.load("get_train_data", ["_compute_detection_E"],
+                   env={"itertools": itertools, "compute_likelihood_linear_filter": cllf})
+rng = np.random.default_rng(2200)
+d = {}
+n_cases = 4
+for i in range(n_cases):
+    F, K = int(rng.integers(3, 9)), int(rng.integers(2, 9))
+    Ls = [int(x) for x in rng.integers(4, 20, size=(1 if i == 0 else int(rng.integers(2, 7))))]
+    bank = tuple(((rng.standard_normal((L, F, K)) * .7).astype(np.float32), float(rng.standard_normal() * 3)) for L in Ls)
+    nutt = 3
+    Tmax = 90
+    det, ids = np.zeros((nutt, Tmax + 2), np.float32), np.zeros((nutt, Tmax + 2), np.int32)
+    lengths, examples = [], []
+    syl = ("aa", "b")
+    with contextlib.redirect_stdout(io.StringIO()):
+        for u in range(nutt):
+            nph = int(rng.integers(3, 9))
+            phns = rng.choice(np.array(["aa", "b", "k"]), size=nph)
+            flts = np.concatenate(([0], np.cumsum(rng.integers(5, 11, size=nph)))).astype(np.int64)
+            T = int(flts[-1])
+            E = (rng.random((T, F, K)) < .3).astype(np.uint8)
+            gtd2["_compute_detection_E"](E, phns, flts, det, ids, lengths, bank, syl, examples)
+            d["E%d_%d" % (i, u)], d["phns%d_%d" % (i, u)], d["flts%d_%d" % (i, u)] = E, phns, flts
+            d["ex%d_%d" % (i, u)] = np.array(list(examples[-1]), np.int64).reshape(-1, 2)
+    for m, (W, c) in enumerate(bank):
+        d["W%d_%d" % (i, m)], d["c%d_%d" % (i, m)] = W, np.float64(c)
+    d["M%d" % i], d["det%d" % i], d["ids%d" % i], d["len%d" % i] = np.int64(len(bank)), det, ids, np.array(lengths, np.int64)
+d["n"] = np.int64(n_cases)
+path = os.path.join(HERE, "g22_compute_detection_E_reftext.npz")
+np.savez_compressed(path, **d)
+print("g22_compute_detection_E_reftext %.1f KB" % (os.path.getsize(path) / 1024))

@@ -216,6 +216,23 @@ def test_g20_classifier_from_the_references_own_code(mods):
                 assert abs(float(got) - x) <= 1e-5 * max(abs(x), 1.0), (i, m)
 
 
+def test_g22_compute_detection_E_from_the_references_own_code(mods):
+    """g22: get_train_data._compute_detection_E (:927-1012) itself over the compiled detect -- the reference's
+    signature, rows appended utterance after utterance, template ids, example times, detect lengths."""
+    import template_speech_rec.get_train_data as gtd
+    g = golden("g22_compute_detection_E_reftext")
+    for i in range(int(g["n"])):
+        bank = tuple((g["W%d_%d" % (i, m)], g["c%d_%d" % (i, m)]) for m in range(int(g["M%d" % i])))
+        det, ids = np.zeros_like(g["det%d" % i]), np.zeros_like(g["ids%d" % i])
+        lengths, examples = [], []
+        for u in range(det.shape[0]):
+            gtd._compute_detection_E(g["E%d_%d" % (i, u)], g["phns%d_%d" % (i, u)], g["flts%d_%d" % (i, u)], det, ids,
+                                     lengths, bank, ("aa", "b"), examples)
+            assert np.array_equal(np.array(examples[-1], np.int64).reshape(-1, 2), g["ex%d_%d" % (i, u)])
+        assert np.array_equal(det, g["det%d" % i]) and np.array_equal(ids, g["ids%d" % i])      # TSR_EXACT: bit for bit
+        assert lengths == [int(x) for x in g["len%d" % i]]
+
+
 # ---- seeded random parity against the oracle, both precision modes ---------------------
 def _check_bank(tsr_hip, oracle, corpus, flags, tol):
     bank = tsr_hip.Bank(corpus["bank"])

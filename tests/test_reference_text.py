@@ -280,3 +280,21 @@ def test_dropin_host_logic_is_the_references_code():
         part[0] = part[n] = 2
         part[1:n][rng.random(n - 1) < .4] = 2
         assert rf.get_cluster_starts_ends(times, part) == r_rf["get_cluster_starts_ends"](times, part)
+
+
+def test_dropin_example_bookkeeping_is_the_references_code():
+    """get_examples_from_phns_ftls / phns_syllable_matches / map_array_to_coarse_coordinates of the product package."""
+    sys.path.insert(0, os.path.join(ROOT, "template-speech-recognition_amd"))
+    import template_speech_rec.get_train_data as gtd
+    r = py2ref.load("get_train_data", ["get_examples_from_phns_ftls"])
+    rng = np.random.default_rng(1809)
+    for case in range(40):
+        n = int(rng.integers(3, 20))
+        phns = rng.choice(np.array(["aa", "b", "k", "s"]), size=n)
+        flts = np.concatenate(([0], np.cumsum(rng.integers(2, 30, size=n)))).astype(np.int64)
+        syl = tuple(rng.choice(np.array(["aa", "b", "k", "s"]), size=int(rng.integers(1, 3))))
+        lpb = None if case % 2 else np.zeros((3, int(rng.integers(2, 6)), 4, 8))
+        want = r["get_examples_from_phns_ftls"](syl, phns, flts, lpb, int(flts[-1]) // 2)
+        got = gtd.get_examples_from_phns_ftls(syl, phns, flts, lpb, int(flts[-1]) // 2)
+        for a, b in zip(want, got):
+            assert (a is None and b is None) or np.array_equal(a, b), case
