@@ -131,8 +131,9 @@ def _compute_detection_E(E, phns, E_flts, detection_array, detection_template_id
     detect_lengths.append(E.shape[0] if len(linear_filters_cs) > 1 else 0)
 
 
-def get_detection_scores(utterances, linear_filters_cs, P_config=None, flags=api.TSR_EXACT, ctx=None):
-    """The corpus loop of get_detection_scores_mixture_named_params (:1238-1339) from
+def get_detection_scores_E(utterances, linear_filters_cs, P_config=None, flags=api.TSR_EXACT, ctx=None):
+    """(Named ..._E, like get_classify_scores_E, because the reference's get_detection_scores is a different,
+    file-driven function.)  The corpus loop of get_detection_scores_mixture_named_params (:1238-1339) from
     the edge maps on: `utterances` is a sequence of binary maps E_n [T_n, F, K]
     (edge maps, or part maps when P_config is None).  Returns
     (detection_array f32 [N, maxT+2], detection_template_ids i32 [N, maxT+2],
