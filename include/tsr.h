@@ -62,7 +62,10 @@ enum {
  *              order one next to thousands of cancelling taps is NOT within 1e-4 of its own
  *              value in this mode -- nor is the reference's f32 result within that of the
  *              exact sum; ask for TSR_W24 or TSR_EXACT there.  A bank whose shortest filter has at
- *              most 4096 taps (L * D) always gets the third limb.
+ *              most 4096 taps (L * D) always gets the third limb, and so does a bank with a
+ *              filter of more than 66 052 taps (16-bit weights times that many set taps would
+ *              overflow the two-limb path's int32 window sums): the weights never get fewer
+ *              than 16 bits.
  *   TSR_FAST | TSR_W24: three limbs (23-bit weights, power-of-two scale),
  *              <= 2^-22 * max|W_m| per set tap, at 1.5x the matrix-core work. */
 enum { TSR_EXACT = 0, TSR_FAST = 1, TSR_W24 = 2 };
@@ -299,7 +302,10 @@ int tsr_corpus_weighted_sums(tsr_ctx *ctx, const tsr_corpus *corpus, const float
  * to the other ranks over any host channel; every rank then calls
  * tsr_dist_init.  tsr_bank_broadcast replaces the contents of `bank` on every
  * rank with rank `root`'s (an ncclBroadcast over xGMI of the device-resident
- * bank buffers); all ranks must have created a bank of identical geometry.
+ * bank buffers); all ranks must have created a bank of identical geometry
+ * (M, D, template lengths): a small header is broadcast and the ranks' verdicts
+ * are reduced first, so a mismatch returns TSR_ERR_INVALID on EVERY rank instead
+ * of hanging or corrupting the collective.
  * No other collective exists on this path: scoring needs no cross-GPU exchange. */
 int tsr_dist_unique_id(char id[128]);
 int tsr_dist_init(tsr_ctx *ctx, const char id[128], int nranks, int rank);

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64) void detect_u8_single_lds_kernel(const uint8_t 
     const int t0 = blockIdx.x * 64, lane = threadIdx.x;
     const int nrows = min(64 + L - 1, T - t0);
     uint8_t *xs = du_smem;                                                        // [nrows][RS]
-    float *ws = reinterpret_cast<float *>(du_smem + (size_t)(64 + L - 1) * RS);   // [L*D]
+    float *ws = reinterpret_cast<float *>(du_smem + (((size_t)(64 + L - 1) * RS + 15) & ~(size_t)15));  // [L*D], 16-byte aligned (b128 accesses)
     const int D4 = D >> 2;
     for (int i = lane; i < nrows * D4; i += 64) {
         const int r = i / D4, c4 = (i - r * D4) * 4;
@@ -353,7 +353,7 @@ int tsr_launch_detect_u8_single(tsr_ctx *ctx, const uint8_t *d_F, int64_t T, int
     if ((D & 7) == 0) {
         int RS = (int)D;
         if (((RS >> 3) & 1) == 0) RS += 8;  // odd number of 8-byte slots: consecutive rows start in different banks
-        const size_t lds = (size_t)(64 + L - 1) * RS + (size_t)(L * D) * 4;
+        const size_t lds = (((size_t)(64 + L - 1) * RS + 15) & ~(size_t)15) + (size_t)(L * D) * 4;
         if (lds <= 128 * 1024) {
             TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(detect_u8_single_lds_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

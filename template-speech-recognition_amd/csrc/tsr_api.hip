@@ -53,6 +53,8 @@ TSR_API int tsr_device_count(int *count)
     return TSR_OK;
 }
 
+TSR_API int tsr_ctx_destroy(tsr_ctx *ctx);
+
 TSR_API int tsr_ctx_create(int device, tsr_ctx **out)
 {
     TSR_REQUIRE(out, "tsr_ctx_create: null out pointer");
@@ -78,9 +80,14 @@ TSR_API int tsr_ctx_create(int device, tsr_ctx **out)
     ctx->cus = prop.multiProcessorCount;
     ctx->hbm_bytes = (int64_t)prop.totalGlobalMem;
     snprintf(ctx->name, sizeof ctx->name, "%s (%s)", prop.name, prop.gcnArchName);
-    TSR_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    TSR_HIP(hipEventCreate(&ctx->ev0));
-    TSR_HIP(hipEventCreate(&ctx->ev1));
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e != hipSuccess) {
+        tsr_set_error("tsr_ctx_create: stream/event creation failed: %s", hipGetErrorString(e));
+        tsr_ctx_destroy(ctx);  // frees whatever was created
+        return TSR_ERR_HIP;
+    }
     *out = ctx;
     return TSR_OK;
 }
@@ -89,7 +96,7 @@ TSR_API int tsr_ctx_destroy(tsr_ctx *ctx)
 {
     if (!ctx) return TSR_OK;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm) tsr_dist_finalize(ctx);
     for (auto &b : ctx->scratch)
         if (b.ptr) (void)hipFree(b.ptr);
@@ -225,19 +232,40 @@ static int bank_build_exact(tsr_ctx *ctx, tsr_bank *b)
                 dst[((int64_t)tau * WR * 32 + d) * TSR_MG + mi] = src[(int64_t)tau * D + d];
         woff += (int64_t)b->L[m] * D;
     }
+    std::vector<float> cf(M);
+    for (int m = 0; m < M; ++m) cf[m] = (float)b->c[m];
+    // new device forms first; the bank's pointers change only when all of them exist, so a failed
+    // (re)build leaves the old, self-consistent bank behind
+    float *n_Wx = nullptr, *n_cf = nullptr;
+    int64_t *n_off = nullptr;
+    int32_t *n_gL = nullptr, *n_L = nullptr;
+    int s = dev_upload(ctx, &n_Wx, Wx.data(), Wx.size());
+    if (s == TSR_OK) s = dev_upload(ctx, &n_off, b->gx_off.data(), b->gx_off.size());
+    if (s == TSR_OK) s = dev_upload(ctx, &n_gL, b->gx_L.data(), b->gx_L.size());
+    if (s == TSR_OK) s = dev_upload(ctx, &n_L, b->L.data(), b->L.size());
+    if (s == TSR_OK) s = dev_upload(ctx, &n_cf, cf.data(), cf.size());
+    if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {  // host staging vectors die here
+        tsr_set_error("bank upload failed");
+        s = TSR_ERR_HIP;
+    }
+    if (s != TSR_OK) {
+        dev_free(n_Wx);
+        dev_free(n_off);
+        dev_free(n_gL);
+        dev_free(n_L);
+        dev_free(n_cf);
+        return s;
+    }
     dev_free(b->d_Wx);
     dev_free(b->d_gx_off);
     dev_free(b->d_gx_L);
     dev_free(b->d_L);
     dev_free(b->d_cf);
-    std::vector<float> cf(M);
-    for (int m = 0; m < M; ++m) cf[m] = (float)b->c[m];
-    TSR_TRY(dev_upload(ctx, &b->d_Wx, Wx.data(), Wx.size()));
-    TSR_TRY(dev_upload(ctx, &b->d_gx_off, b->gx_off.data(), b->gx_off.size()));
-    TSR_TRY(dev_upload(ctx, &b->d_gx_L, b->gx_L.data(), b->gx_L.size()));
-    TSR_TRY(dev_upload(ctx, &b->d_L, b->L.data(), b->L.size()));
-    TSR_TRY(dev_upload(ctx, &b->d_cf, cf.data(), cf.size()));
-    TSR_HIP(hipStreamSynchronize(ctx->stream));  // host staging vectors die here
+    b->d_Wx = n_Wx;
+    b->d_gx_off = n_off;
+    b->d_gx_L = n_gL;
+    b->d_L = n_L;
+    b->d_cf = n_cf;
     return TSR_OK;
 }
 
@@ -439,6 +467,10 @@ static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp,
         int32_t Lmin = bank->Lmax;
         for (int32_t l : bank->L) Lmin = std::min(Lmin, l);
         if ((int64_t)Lmin * bank->D <= TSR_FAST_W24_BELOW_TAPS) flags |= TSR_W24;  // (the shortest filter decides)
+        // Very long filters: 16-bit weights times more than 66 052 set taps no longer fit the two-limb
+        // path's int32 window sums; rather than shave bits off the weights (which would break the
+        // "at least 16-bit" bound of include/tsr.h) the bank takes three limbs and the int64 ring.
+        if ((int64_t)bank->Lmax * bank->D > TSR_FAST_W24_ABOVE_TAPS) flags |= TSR_W24;
     }
     if (flags & TSR_FAST) {
         const int NL = (flags & TSR_W24) ? 3 : 2;
@@ -1448,6 +1480,7 @@ struct rccl_api {
     int (*GetUniqueId)(void *) = nullptr;
     int (*CommInitRank)(void **, int, uid128, int) = nullptr;
     int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
@@ -1484,9 +1517,10 @@ static int rccl_load()
     g_rccl.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (int (*)(void **, int, uid128, int))dlsym(h, "ncclCommInitRank");
     g_rccl.Broadcast = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclBroadcast");
+    g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
     g_rccl.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
     g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.Broadcast || !g_rccl.CommDestroy) {
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.Broadcast || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
         tsr_set_error("RCCL: librccl lacks a required symbol");
         dlclose(h);
         return TSR_ERR_RCCL;
@@ -1552,26 +1586,54 @@ TSR_API int tsr_bank_broadcast(tsr_ctx *ctx, tsr_bank *bank, int root)
     const size_t offC = ((size_t)bank->M * 4 + 7) & ~(size_t)7;
     const size_t offW = offC + (size_t)bank->M * 8;
     const size_t bytes = offW + nW * 4;
+    // 1) geometry header {M, D, sumL, hash of L[]} from the root; every rank compares it with its own
+    //    bank and the verdicts are MIN-reduced, so that either all ranks go on to the payload (whose
+    //    byte count then agrees everywhere) or all of them return TSR_ERR_INVALID -- a mismatch can
+    //    neither hang the collective nor corrupt a bank.
+    int64_t hdr[4] = {bank->M, bank->D, bank->sumL, 1469598103934665603ll};
+    for (int32_t l : bank->L) hdr[3] = (hdr[3] ^ (int64_t)l) * 1099511628211ll;  // FNV-1a over the lengths
+    void *d = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_W, std::max<size_t>(bytes, 64), &d));
+    TSR_HIP(hipMemcpyAsync(d, hdr, sizeof hdr, hipMemcpyHostToDevice, ctx->stream));
+    TSR_NCCL(g_rccl.Broadcast(d, d, sizeof hdr, /*ncclChar*/ 0, root, ctx->comm, ctx->stream));
+    int64_t got[4];
+    TSR_HIP(hipMemcpyAsync(got, d, sizeof got, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    int32_t same = memcmp(got, hdr, sizeof hdr) == 0 ? 1 : 0;
+    int32_t *d_flag = reinterpret_cast<int32_t *>(static_cast<char *>(d) + 32);
+    TSR_HIP(hipMemcpyAsync(d_flag, &same, 4, hipMemcpyHostToDevice, ctx->stream));
+    TSR_NCCL(g_rccl.AllReduce(d_flag, d_flag, 1, /*ncclInt32*/ 2, /*ncclMin*/ 3, ctx->comm, ctx->stream));
+    int32_t all_same = 0;
+    TSR_HIP(hipMemcpyAsync(&all_same, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    if (!all_same) {
+        if (same)
+            tsr_set_error("tsr_bank_broadcast: another rank's bank geometry differs from root %d's", root);
+        else
+            tsr_set_error("tsr_bank_broadcast: rank %d's bank geometry (M=%d D=%lld sumL=%lld, template lengths) "
+                          "differs from root's (M=%lld D=%lld sumL=%lld)", ctx->rank, bank->M, (long long)bank->D,
+                          (long long)bank->sumL, (long long)got[0], (long long)got[1], (long long)got[2]);
+        return TSR_ERR_INVALID;
+    }
+    // 2) the payload
     std::vector<char> host(bytes, 0);
     memcpy(host.data(), bank->L.data(), (size_t)bank->M * 4);
     memcpy(host.data() + offC, bank->c.data(), (size_t)bank->M * 8);
     memcpy(host.data() + offW, bank->W_cat.data(), nW * 4);
-    void *d = nullptr;
-    TSR_TRY(tsr_scratch(ctx, SLOT_W, bytes, &d));
     TSR_HIP(hipMemcpyAsync(d, host.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
     TSR_NCCL(g_rccl.Broadcast(d, d, bytes, /*ncclChar*/ 0, root, ctx->comm, ctx->stream));
     std::vector<char> back(bytes);
     TSR_HIP(hipMemcpyAsync(back.data(), d, bytes, hipMemcpyDeviceToHost, ctx->stream));
     TSR_HIP(hipStreamSynchronize(ctx->stream));
     if (memcmp(back.data(), bank->L.data(), (size_t)bank->M * 4) != 0) {
-        tsr_set_error("tsr_bank_broadcast: rank %d's bank geometry (template lengths) differs from root's", ctx->rank);
+        tsr_set_error("tsr_bank_broadcast: rank %d's template lengths differ from root's", ctx->rank);
         return TSR_ERR_INVALID;
     }
     if (ctx->rank != root) {
         memcpy(bank->c.data(), back.data() + offC, (size_t)bank->M * 8);
         memcpy(bank->W_cat.data(), back.data() + offW, nW * 4);
+        tsr_fast_bank_free(bank);  // limb tables of the old weights go first: rebuilt lazily from the new ones
         TSR_TRY(bank_build_exact(ctx, bank));
-        tsr_fast_bank_free(bank);  // rebuilt lazily from the new weights
     }
     return TSR_OK;
 }

@@ -74,6 +74,9 @@ int tsr_corpus_create_empty(tsr_ctx *ctx, const int64_t *frame_offsets, int64_t 
 
 // TSR_FAST uses three limbs when the SHORTEST filter of the bank has at most this many taps (Lmin * D).
 #define TSR_FAST_W24_BELOW_TAPS 4096
+// ... and when ANY filter has more than this many taps: the two-limb path keeps its window sums in an
+// int32 ring, which holds 16-bit weights (|q| <= 127*256) only up to floor((2^31-1) / (127*256)) set taps.
+#define TSR_FAST_W24_ABOVE_TAPS 66052
 
 // Fast (MFMA) path: see detect_mfma_kernel.inc for the limb layout.
 struct tsr_bank {

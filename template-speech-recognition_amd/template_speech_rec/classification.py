@@ -9,6 +9,8 @@ scores EVERY window of a whole [D, T] utterance in one launch (what the ROC
 harnesses do with a Python loop over `d`, classification.py:459-461, 601-603).
 The ROC harnesses themselves are outside the accelerated path.
 """
+import hashlib
+
 import numpy as np
 
 from tsr_hip import api
@@ -123,10 +125,15 @@ class Classifier:
     # ---- whole-utterance scoring (one launch for all windows) --------------------------
     def _bank(self, bg):
         bgd = np.asarray(self.template.bg if self.type == "TwoPartModel" else bg, np.float64)
-        key = bgd.tobytes()
+        members = [np.ascontiguousarray(np.asarray(t, np.float64)) for t in self._members(bgd)]
+        h = hashlib.blake2b(bgd.tobytes(), digest_size=16)  # content key: templates may be updated in place
+        for t in members:
+            h.update(repr(t.shape).encode())
+            h.update(t.tobytes())
+        key = h.digest()
         if self._bank_cache is None or self._bank_cache[0] != key:
             filters = []
-            for tmpl in self._members(bgd):
+            for tmpl in members:
                 Tm = np.ascontiguousarray(np.asarray(tmpl, np.float64).T)  # [L, D]
                 neg = (1. - Tm) / (1. - bgd)
                 filters.append((np.log((Tm / bgd) / neg).astype(np.float32), float(np.log(neg).sum())))

@@ -15,6 +15,8 @@ Waveform -> spectrogram -> edge map (edge_signal_proc.py) is upstream of the
 path and stays with the caller: every function here starts from the binary
 edge map E.
 """
+import hashlib
+
 import numpy as np
 
 from tsr_hip import api
@@ -44,16 +46,21 @@ def collapse_to_grid(E_coded, grid_time, grid_frequency):
 _parts_cache = {}
 
 
+def _digest(a):
+    a = np.ascontiguousarray(a)
+    return hashlib.blake2b(a.tobytes(), digest_size=16).digest(), a.shape, a.dtype.str
+
+
 def _device_parts(log_parts, log_invparts):
-    key = (id(log_parts), id(log_invparts))
+    # keyed by CONTENT: part re-estimation loops update logParts / logInvParts in place
+    key = (_digest(log_parts), _digest(log_invparts))
     hit = _parts_cache.get(key)
-    if hit is None or hit[0] is not log_parts or hit[1] is not log_invparts:
+    if hit is None:
         if len(_parts_cache) > 8:
             _parts_cache.clear()
-        hit = (log_parts, log_invparts, api.Parts(np.asarray(log_parts, np.float64),
-                                                  np.asarray(log_invparts, np.float64)))
+        hit = api.Parts(np.asarray(log_parts, np.float64), np.asarray(log_invparts, np.float64))
         _parts_cache[key] = hit
-    return hit[2]
+    return hit
 
 
 def get_part_features(E, parameters, verbose=False):

@@ -6,6 +6,8 @@ and evaluates sum(E * log W) and C in float64 NumPy.  Here the filter is built
 once per (template, bgd) pair, cached, and the window sum runs through the same
 kernel as compute_likelihood_linear_filter.detect (float32, reference order),
 which agrees with the float64 value to ~1e-6 relative."""
+import hashlib
+
 import numpy as np
 
 from . import compute_likelihood_linear_filter as cllf
@@ -14,11 +16,14 @@ _filter_cache = {}
 
 
 def _window_filter(template, bgd, front_bgd_pad, back_bgd_pad):
-    key = (template.__array_interface__["data"][0], template.shape, np.asarray(bgd).tobytes(),
-           front_bgd_pad, back_bgd_pad)
+    # keyed by CONTENT (a digest of the bytes), not by object identity: callers re-estimate templates
+    # in place between calls
+    template = np.asarray(template)
+    key = (hashlib.blake2b(np.ascontiguousarray(template).tobytes(), digest_size=16).digest(), template.shape,
+           template.dtype.str, np.asarray(bgd).tobytes(), front_bgd_pad, back_bgd_pad)
     hit = _filter_cache.get(key)
-    if hit is not None and hit[0] is template:
-        return hit[1], hit[2]
+    if hit is not None:
+        return hit
     bgd = np.asarray(bgd, dtype=np.float64)
     col = bgd.reshape(-1, 1)
     full = np.hstack((np.tile(col, (1, front_bgd_pad)), np.asarray(template, np.float64),
@@ -30,7 +35,7 @@ def _window_filter(template, bgd, front_bgd_pad, back_bgd_pad):
     C = float(np.log(neg).sum())
     if len(_filter_cache) > 64:
         _filter_cache.clear()
-    _filter_cache[key] = (template, W, C)
+    _filter_cache[key] = (W, C)
     return W, C
 
 

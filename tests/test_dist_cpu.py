@@ -1,7 +1,8 @@
-"""world_size-2 gloo tests (CPU) of the multi-GPU host logic: utterance sharding, the RCCL
-unique-id hand-over, placeholder banks, max-over-ranks timing and score gathering.  The GPU
-work itself needs no collective; what is exercised here is everything around it that bench.py
-relies on for N > 1."""
+"""world_size-2 tests (CPU) of the multi-GPU host logic: utterance sharding, the RCCL unique-id
+hand-over, placeholder banks, max-over-ranks timing and score gathering -- once over the
+package's own stdlib-socket control plane (tsr_hip.dist.HostGroup, what bench.py uses) and once
+over torch.distributed/gloo.  The GPU work itself needs no collective; what is exercised here is
+everything around it that bench.py relies on for N > 1."""
 import os
 import socket
 import sys
@@ -35,31 +36,36 @@ def _free_port():
     return p
 
 
+def _exercise(dist, rank, world):
+    uid = tdist.exchange_unique_id(dist, lambda: bytes(range(128)))
+    assert uid == bytes(range(128))
+    # utterance-sharded scoring with a stand-in scorer (per-frame sum): every rank handles
+    # its own utterances, nothing is exchanged until the gather
+    rng = np.random.default_rng(5)
+    lengths = rng.integers(3, 30, size=41)
+    feats = rng.integers(0, 2, size=(int(lengths.sum()), 6)).astype(np.uint8)
+    offs = np.concatenate(([0], np.cumsum(lengths)))
+    b = tdist.shard_utterances(lengths, world)
+    lo, hi = int(offs[b[rank]]), int(offs[b[rank + 1]])
+    local_scores = feats[lo:hi].sum(1).astype(np.float32)
+    local_ids = np.full(hi - lo, rank, np.int32)
+    s, i = tdist.gather_scores(dist, local_scores, local_ids, offs)
+    assert np.array_equal(s, feats.sum(1).astype(np.float32))
+    assert np.array_equal(i[:int(offs[b[1]])], np.zeros(int(offs[b[1]]), np.int32))
+    mx = tdist.max_over_ranks(dist, float(rank + 1), 10.0 - rank)
+    assert mx == [float(world), 10.0]
+    pb = tdist.placeholder_bank([3, 5], (4, 2))
+    assert [w.shape for w, _ in pb] == [(3, 4, 2), (5, 4, 2)] and not pb[0][0].any()
+    assert tdist.broadcast_object(dist, {"bank": rank} if rank == 0 else None) == {"bank": 0}
+    dist.barrier()
+
+
 def _worker(rank, world, port, out):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        uid = tdist.exchange_unique_id(dist, lambda: bytes(range(128)))
-        assert uid == bytes(range(128))
-        # utterance-sharded scoring with a stand-in scorer (per-frame sum): every rank handles
-        # its own utterances, nothing is exchanged until the gather
-        rng = np.random.default_rng(5)
-        lengths = rng.integers(3, 30, size=41)
-        feats = rng.integers(0, 2, size=(int(lengths.sum()), 6)).astype(np.uint8)
-        offs = np.concatenate(([0], np.cumsum(lengths)))
-        b = tdist.shard_utterances(lengths, world)
-        lo, hi = int(offs[b[rank]]), int(offs[b[rank + 1]])
-        local_scores = feats[lo:hi].sum(1).astype(np.float32)
-        local_ids = np.full(hi - lo, rank, np.int32)
-        s, i = tdist.gather_scores(dist, local_scores, local_ids, offs)
-        assert np.array_equal(s, feats.sum(1).astype(np.float32))
-        assert np.array_equal(i[:int(offs[b[1]])], np.zeros(int(offs[b[1]]), np.int32))
-        mx = tdist.max_over_ranks(dist, float(rank + 1), 10.0 - rank)
-        assert mx == [float(world), 10.0]
-        pb = tdist.placeholder_bank([3, 5], (4, 2))
-        assert [w.shape for w, _ in pb] == [(3, 4, 2), (5, 4, 2)] and not pb[0][0].any()
-        dist.barrier()
+        _exercise(dist, rank, world)
         out.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         out.put((rank, repr(e)))
@@ -67,15 +73,59 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_world_size_2_gloo():
-    import torch.multiprocessing as mp
+def _worker_sockets(rank, world, port, out, via_env):
+    try:
+        if via_env:  # the way bench.py builds it under a launcher: env + port file
+            os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                              TORCHELASTIC_RUN_ID="pytest%d" % port)
+            os.environ.pop("TSR_CTRL_PORT", None)
+            g = tdist.HostGroup.from_env(timeout=60)
+        else:
+            g = tdist.HostGroup(rank, world, "127.0.0.1", port, timeout=60)
+        try:
+            _exercise(g, rank, world)
+            out.put((rank, "ok"))
+        finally:
+            g.close()
+    except Exception as e:  # pragma: no cover
+        out.put((rank, repr(e)))
+
+
+def _run(target, world, extra=()):
+    import multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, world, port, out) + tuple(extra)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(out.get(timeout=120) for _ in procs)
     for p in procs:
         p.join(60)
-    assert res == {0: "ok", 1: "ok"}, res
+    return res
+
+
+def test_world_size_2_host_group_sockets():
+    assert _run(_worker_sockets, 2, (False,)) == {0: "ok", 1: "ok"}
+
+
+def test_world_size_3_host_group_from_env():
+    assert _run(_worker_sockets, 3, (True,)) == {0: "ok", 1: "ok", 2: "ok"}
+
+
+def test_host_group_world_size_1_is_local():
+    g = tdist.HostGroup(0, 1)
+    assert g.allgather(5) == [5] and tdist.max_over_ranks(g, 1.5, 2.0) == [1.5, 2.0]
+    g.barrier()
+    g.close()
+
+
+def test_product_package_does_not_import_torch():
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import tsr_hip.dist, tsr_hip.synth; "
+            "assert 'torch' not in sys.modules" % os.path.join(ROOT, "template-speech-recognition_amd"))
+    assert subprocess.run([sys.executable, "-c", code]).returncode == 0
+
+
+def test_world_size_2_gloo():
+    assert _run(_worker, 2) == {0: "ok", 1: "ok"}

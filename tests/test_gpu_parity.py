@@ -309,6 +309,172 @@ def test_config2_full_size_properties(mods, oracle):
     assert np.array_equal(s2, s[offs[500]:]) and np.array_equal(a2, a[offs[500]:])
 
 
+# ---- the benchmarked kernel under a checker at the benchmark's size -------------------------------
+def _fast_all_frames(tsr_hip, oracle, c, flags, n_oracle=12, seed=0, check_exact=False):
+    """Every frame of the corpus, fused scores + ids AND the per-template scores, TSR_FAST[|W24] against
+    TSR_EXACT (the bit-identical kernel, itself held to the oracle elsewhere and on a sample here);
+    then a seeded sample of utterances straight against the oracle.  At this size the MFMA kernel runs
+    its steady-state iteration, cuts segments inside utterances and reads halo rows."""
+    feats, offs = c["feats"], c["offsets"]
+    P, N = int(offs[-1]), len(offs) - 1
+    bank = tsr_hip.Bank(c["bank"])
+    dc = tsr_hip.Corpus(feats.reshape(P, -1), offs)
+    dc.score(bank, tsr_hip.TSR_EXACT)
+    se, ae = dc.download()
+    alle = dc.score_all(bank, tsr_hip.TSR_EXACT)
+    dc.score(bank, flags)
+    sf, af = dc.download()
+    allf = dc.score_all(bank, flags)
+    assert rel_err(sf, se) <= TOL and rel_err(allf, alle) <= TOL
+    if alle.shape[0] > 1:
+        top2 = np.sort(alle, axis=0)[-2:]
+        clear = (top2[1] - top2[0]) > TOL * np.maximum(np.abs(top2[1]), 1.0)
+        assert np.array_equal(af[clear], ae[clear])
+        assert clear.mean() > 0.5
+    # the fused pass and the all-scores pass of the fast path agree bit for bit (exact integer sums)
+    assert np.array_equal(allf.max(0), sf)
+    rng = np.random.default_rng(seed)
+    lens = np.diff(offs)
+    cand = np.flatnonzero(lens > 0)
+    for n in rng.choice(cand, size=min(n_oracle, len(cand)), replace=False):
+        sl = slice(int(offs[n]), int(offs[n + 1]))
+        so, ao = oracle.score_bank(feats[sl], c["bank"])
+        assert rel_err(sf[sl], so) <= TOL, n
+        if check_exact:
+            assert np.array_equal(se[sl], so) and np.array_equal(ae[sl], ao), n
+    dc.close()
+    bank.close()
+    return se, sf
+
+
+@pytest.mark.parametrize("flags", [1, 3], ids=["fast16", "fast24"])
+@pytest.mark.parametrize("L", [32, [20, 24, 28, 32, 36, 40, 44, 48]], ids=["config2a", "config2b"])
+def test_config2_full_size_fast_all_frames(mods, oracle, L, flags):
+    """BASELINE config 2 (1000 x 200 frames, D = 360, M = 8; 2a: L = 32, 2b: L_m = 20..48) -- the
+    configuration bench.py times -- in both MFMA precisions, all 200 000 frames."""
+    tsr_hip = mods[3]
+    from tsr_hip import synth
+    c = synth.corpus(2, N=1000, T=200, F=45, E=8, M=8, L=L)
+    _fast_all_frames(tsr_hip, oracle, c, flags, check_exact=(flags == 1))
+
+
+@pytest.mark.parametrize("flags", [1, 3], ids=["fast16", "fast24"])
+def test_ragged_large_corpus_fast_all_frames(mods, oracle, flags):
+    """P > 60 000 frames of ragged utterances (T_n in 0..400, some shorter than every template) with
+    variable template lengths: the steady-state tiles meet utterance boundaries mid-segment."""
+    tsr_hip = mods[3]
+    from tsr_hip import synth
+    rng = np.random.default_rng(606)
+    T = rng.integers(1, 401, size=420)
+    T[rng.choice(420, size=12, replace=False)] = rng.integers(0, 20, size=12)
+    c = synth.corpus(606, N=420, T=T, F=45, E=8, M=8, L=[20, 24, 28, 32, 36, 40, 44, 48])
+    assert int(c["offsets"][-1]) >= 60000
+    _fast_all_frames(tsr_hip, oracle, c, flags, n_oracle=16, seed=1, check_exact=(flags == 1))
+
+
+def test_utterance_longer_than_the_references_uint16_cap(mods, oracle):
+    """One utterance of T = 70 000 frames: the reference stores T in a uint16
+    (compute_likelihood_linear_filter.pyx:153-157) and cannot score it; here the frame axis is tiled with
+    an Lmax-1 halo, so T is bounded only by memory.  Exact: bit for bit against the oracle's 64-bit loop;
+    the drop-in detect and both MFMA precisions as well."""
+    cllf, tsr_hip = mods[0], mods[3]
+    from tsr_hip import synth
+    c = synth.corpus(70, N=1, T=70000, F=45, E=8, M=2, L=[32, 41])
+    feats, offs = c["feats"], c["offsets"]
+    so, ao = oracle.score_bank(feats, c["bank"])
+    bank = tsr_hip.Bank(c["bank"])
+    s, a = bank.score(feats, offs, flags=tsr_hip.TSR_EXACT)
+    assert np.array_equal(s, so) and np.array_equal(a, ao)
+    for flags in (tsr_hip.TSR_FAST, tsr_hip.TSR_FAST | tsr_hip.TSR_W24):
+        sf, af = bank.score(feats, offs, flags=flags)
+        assert rel_err(sf, so) <= TOL
+    raw = cllf.detect(feats, c["bank"][0][0])
+    assert raw.shape == (70000,) and np.array_equal(raw, oracle.detect(feats, c["bank"][0][0]))
+
+
+def test_very_long_filters_keep_16_bit_weights(mods, oracle):
+    """D = 2050 part features x L = 48 = 98 400 taps per template: past the 66 052 taps up to which 16-bit
+    weights fit the two-limb path's int32 window sums.  TSR_FAST must then take the third limb rather than
+    fewer bits per weight; the documented bound (include/tsr.h: <= 2^-16 max|W_m| per SET tap) is checked."""
+    tsr_hip = mods[3]
+    from tsr_hip import synth
+    c = synth.corpus(48, N=2, T=[70, 49], F=41, E=50, M=3, L=[48, 48, 40])
+    feats, offs = c["feats"], c["offsets"]
+    bank = tsr_hip.Bank(c["bank"])
+    exact = bank.score_all(feats, offs, flags=tsr_hip.TSR_EXACT)
+    fast = bank.score_all(feats, offs, flags=tsr_hip.TSR_FAST)
+    w24 = bank.score_all(feats, offs, flags=tsr_hip.TSR_FAST | tsr_hip.TSR_W24)
+    assert np.array_equal(fast, w24)                      # promoted: the very same three-limb pass
+    ones = tsr_hip.Bank([(np.ones_like(W), 0.0) for W, _ in c["bank"]]).score_all(feats, offs)   # set taps per window
+    alle = np.concatenate([oracle.score_bank_all(feats[offs[n]:offs[n + 1]], c["bank"]) for n in range(2)], axis=1)
+    assert np.array_equal(exact, alle)
+    for m, (W, cc) in enumerate(c["bank"]):
+        # + the f32 rounding of both sums (the reference's own sequential sum is no better than that)
+        bound = 2.0 ** -16 * float(np.abs(W).max()) * ones[m] + 64 * np.spacing(np.abs(exact[m]).astype(np.float32))
+        assert np.all(np.abs(fast[m].astype(np.float64) - exact[m]) <= bound), m
+    assert rel_err(fast, exact) <= TOL
+
+
+# ---- multi-GPU: the one collective of the path, for real (RCCL, one rank on this box's GPU) ----------
+def test_rccl_bank_broadcast_single_rank(mods, oracle):
+    """tsr_dist_unique_id -> tsr_dist_init(nranks=1) -> tsr_bank_broadcast(root 0) -> same scores ->
+    tsr_dist_finalize: ncclCommInitRank, the header broadcast, the all-reduce of the geometry verdicts and
+    the payload ncclBroadcast all run through librccl on the device."""
+    tsr_hip = mods[3]
+    from tsr_hip import synth
+    ctx = tsr_hip.Context(0)
+    uid = tsr_hip.unique_id()
+    assert len(uid) == 128 and any(uid)
+    ctx.dist_init(uid, 1, 0)
+    with open("/proc/self/maps") as f:
+        assert "librccl" in f.read()
+    c = synth.corpus(5, N=7, T=[60, 48, 33, 80, 64, 10, 200], F=45, E=8, M=5, L=[9, 12, 32, 20, 11])
+    bank = tsr_hip.Bank(c["bank"], ctx=ctx)
+    so, ao = oracle.score_corpus(c["feats"], c["offsets"], c["bank"])
+    s0, a0 = bank.score(c["feats"], c["offsets"], flags=tsr_hip.TSR_EXACT)
+    f0, _ = bank.score(c["feats"], c["offsets"], flags=tsr_hip.TSR_FAST)
+    bank.broadcast(0)
+    s1, a1 = bank.score(c["feats"], c["offsets"], flags=tsr_hip.TSR_EXACT)
+    f1, _ = bank.score(c["feats"], c["offsets"], flags=tsr_hip.TSR_FAST)
+    assert np.array_equal(s0, so) and np.array_equal(a0, ao)
+    assert np.array_equal(s1, so) and np.array_equal(a1, ao) and np.array_equal(f1, f0)
+    with pytest.raises(ValueError):
+        bank.broadcast(1)                                   # root out of range (TSR_ERR_INVALID)
+    ctx.dist_finalize()
+    with pytest.raises(ValueError):
+        bank.broadcast(0)                                   # no communicator any more
+    bank.close()
+    ctx.close()
+
+
+def test_device_caches_follow_in_place_updates(mods, oracle):
+    """The drop-in modules cache device tables by content: updating logParts or a template in place
+    (EM / re-estimation loops do) must not return stale features or scores."""
+    from collections import namedtuple
+    from template_speech_rec import get_train_data as gtrd
+    from template_speech_rec import test_template as tt
+    from tsr_hip import synth
+    rng = np.random.default_rng(17)
+    X = synth.features(rng, 30, rng.uniform(0.05, 0.45, size=(12, 8)))
+    lp, lip = synth.parts(rng, 6)
+    PP = namedtuple("PartsParameters", "logParts logInvParts bernsteinEdgeThreshold spreadRadiusX "
+                                       "spreadRadiusY numParts partGraph")
+    p = PP(lp, lip, 8, 1, 1, 6, None)
+    a = gtrd.get_part_features(X, p)
+    assert np.array_equal(a, oracle.get_part_features(X, lp, lip, 8, 1, 1, 6))
+    lp[:], lip[:] = synth.parts(rng, 6)                     # in place: same objects, new contents
+    b = gtrd.get_part_features(X, p)
+    assert np.array_equal(b, oracle.get_part_features(X, lp, lip, 8, 1, 1, 6)) and not np.array_equal(a, b)
+    tmpl = rng.uniform(0.05, 0.95, size=(24, 7))
+    bg = rng.uniform(0.05, 0.4, size=24)
+    E = (rng.random((24, 7)) < 0.3).astype(np.uint8)
+    v0 = sum(tt.score_template_background_section(tmpl, bg, E))
+    tmpl[:] = rng.uniform(0.05, 0.95, size=(24, 7))
+    v1 = sum(tt.score_template_background_section(tmpl, bg, E))
+    want = sum(oracle.score_template_background_section(tmpl, bg, E))
+    assert abs(v1 - want) <= 1e-5 * max(abs(want), 1) and abs(v0 - v1) > 1e-6
+
+
 # ---- device-resident front-end chain: edge corpus -> part corpus -> scores (config 3) ----------
 @pytest.mark.parametrize("variant", ["parts", "parts_graph", "waliji"])
 def test_corpus_part_features_chain(mods, oracle, variant):
