@@ -23,10 +23,21 @@ _i64, _i32, _int = C.c_int64, C.c_int32, C.c_int
 _p = C.c_void_p
 
 
+# TSR_ORACLE_SANITIZE=1: the same source built with AddressSanitizer + UndefinedBehaviorSanitizer (CPU build
+# only; tests/test_sanitizers_cpu.py runs the oracle tests against it in a child process with libasan preloaded)
+_SANITIZE = os.environ.get("TSR_ORACLE_SANITIZE") == "1"
+if _SANITIZE:
+    _LIB = os.path.join(_HERE, "liboracle_san.so")
+
+
 def build(force=False):
     """gcc -O2 -ffp-contract=off (no -ffast-math): summation order preserved."""
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(_SRC):
-        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared",
+        flags = ["-O2"]
+        if _SANITIZE:
+            flags = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+                     "-fno-sanitize-recover=undefined"]
+        subprocess.check_call(["gcc"] + flags + ["-ffp-contract=off", "-fPIC", "-shared",
                                "-fvisibility=hidden", "-o", _LIB, _SRC, "-lm"])
     return _LIB
 

@@ -358,6 +358,72 @@ int tsr_launch_mstep(tsr_ctx *ctx, const uint8_t *d_X, int64_t P, int D, int Dp,
     return TSR_OK;
 }
 
+// ---- Bernoulli-mixture E-step epilogue (bernoulli_mixture.py:263-285) ----------------------------------
+// From the per-component scores log P(x_n | k) (the bank pass, [K][P] f32) and the log mixture weights:
+// per data point the log marginal by a max-shifted log-sum-exp and the posterior component probabilities
+// ("affinities"; one-hot on the best-scoring component with hard assignment, :278-281), all in f64 with one
+// rounding to f32 at the end.  One lane per data point; the scores of consecutive points are consecutive, so
+// every load is coalesced.  The log-likelihood is summed per block in a fixed tree order and the block sums
+// (and the per-block column sums of the affinities, i.e. the M-step's new weights) are added up by the host
+// in block order: bit-reproducible from run to run.
+namespace {
+__global__ __launch_bounds__(kThreads) void mixture_estep_kernel(const float *__restrict__ scores, int64_t P, int K,
+                                                                 const double *__restrict__ log_w, int hard,
+                                                                 float *__restrict__ aff /*[P][K]*/,
+                                                                 double *__restrict__ blk /*[blocks][1 + K]*/)
+{
+    __shared__ double red[kThreads];
+    const int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const bool live = n < P;
+    double ll = 0.0;
+    if (live) {
+        double m = -INFINITY;
+        float best_s = 0.0f;
+        int best_k = 0;
+        for (int k = 0; k < K; ++k) {
+            const float s = scores[(int64_t)k * P + n];
+            m = fmax(m, (double)s + log_w[k]);
+            if (k == 0 || s > best_s) {  // np.argmax: first maximum of the template scores (weights not applied, :280)
+                best_s = s;
+                best_k = k;
+            }
+        }
+        double sum = 0.0;
+        for (int k = 0; k < K; ++k) sum += exp((double)scores[(int64_t)k * P + n] + log_w[k] - m);
+        ll = log(sum) + m;
+        for (int k = 0; k < K; ++k) {
+            const double a = hard ? (k == best_k ? 1.0 : 0.0) : exp((double)scores[(int64_t)k * P + n] + log_w[k] - m) / sum;
+            aff[n * K + k] = (float)a;
+        }
+    }
+    // block sums: [0] log-likelihood, [1 + k] column k of the affinities (as stored, f32 values)
+    for (int q = 0; q <= K; ++q) {
+        double v = 0.0;
+        if (live) v = q == 0 ? ll : (double)aff[n * K + q - 1];
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int s = kThreads / 2; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) blk[(int64_t)blockIdx.x * (K + 1) + q] = red[0];
+        __syncthreads();
+    }
+}
+}  // namespace
+
+int tsr_launch_mixture_estep(tsr_ctx *ctx, const float *d_scores, int64_t P, int K, const double *d_log_w, int hard,
+                             float *d_aff, double *d_blk, int *n_blocks)
+{
+    const int blocks = (int)((P + kThreads - 1) / kThreads);
+    *n_blocks = blocks;
+    if (P <= 0) return TSR_OK;
+    hipLaunchKernelGGL(mixture_estep_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, ctx->stream, d_scores, P, K, d_log_w,
+                       hard, d_aff, d_blk);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+
 // ---- detection clustering: cluster_times.pyx:133-222 / :221-310 + roc_functions.py:189-210 --
 // The reference's state machine over the ascending peak times of one utterance is inherently sequential and
 // tiny (a handful of peaks); one LANE per utterance runs it on the peak lists tsr_launch_peaks left on the

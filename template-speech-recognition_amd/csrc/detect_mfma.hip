@@ -328,9 +328,10 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
     // emission trails the MFMAs by one tile, finishing trails emission by one barrier and the
     // utt_end row of tile t+2 is DMA'd while tile t-lag-2 is finished: lag + 5 tiles
     int lag = (bank->Lmax - 1 + 31) / 32;
+    // (alt_bank_kernel copies tiles four ahead into five buffers and finishes one tile later: lag + 8)
     int ring = 32;
-    while (ring < 32 * (lag + 5)) ring *= 2;
-    const size_t lds = (size_t)3 * tile_bytes + (size_t)kMaxSlots * sizeof(SlotMeta) +
+    while (ring < 32 * (lag + 8)) ring *= 2;
+    const size_t lds = (size_t)5 * tile_bytes + (size_t)kMaxSlots * sizeof(SlotMeta) +
                        (size_t)(ring + 64) * 4 + (size_t)ring * 8 +
                        (size_t)(fb->max_slots + 1) * (ring + 33) * (NL == 2 ? 4 : 8) + 16;
     if (lds > 160 * 1024) {

@@ -1,9 +1,7 @@
-// Instantiations of the MFMA bank kernel for NKB = 5..8 (see detect_mfma_kernel.inc).
+// Instantiations of the MFMA bank kernel for NKB = 3, 4 (see detect_mfma_kernel.inc).
 #include "detect_mfma_kernel.inc"
 
 namespace tsr_fast {
-template int launch<5>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
-template int launch<6>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
-template int launch<7>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
-template int launch<8>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
+template int launch<3>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
+template int launch<4>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
 }  // namespace tsr_fast

@@ -1,9 +1,7 @@
-// Instantiations of the MFMA bank kernel for NKB = 9..12 (see detect_mfma_kernel.inc).
+// Instantiations of the MFMA bank kernel for NKB = 5, 6 (see detect_mfma_kernel.inc).
 #include "detect_mfma_kernel.inc"
 
 namespace tsr_fast {
-template int launch<9>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
-template int launch<10>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
-template int launch<11>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
-template int launch<12>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
+template int launch<5>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
+template int launch<6>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
 }  // namespace tsr_fast

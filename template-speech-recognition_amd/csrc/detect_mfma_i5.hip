@@ -1,0 +1,7 @@
+// Instantiations of the MFMA bank kernel for NKB = 11, 12 (see detect_mfma_kernel.inc).
+#include "detect_mfma_kernel.inc"
+
+namespace tsr_fast {
+template int launch<11>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
+template int launch<12>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
+}  // namespace tsr_fast

@@ -440,6 +440,7 @@ TSR_API int tsr_corpus_destroy(tsr_corpus *cp)
     dev_free(cp->d_scores);
     dev_free(cp->d_ids);
     dev_free(cp->d_plan);
+    dev_free(cp->d_aff);
     delete cp;
     return TSR_OK;
 }
@@ -986,6 +987,85 @@ TSR_API int tsr_corpus_weighted_sums(tsr_ctx *ctx, const tsr_corpus *cp, const f
     TSR_HIP(hipMemcpyAsync(out, dO, (size_t)(K * D) * 4, hipMemcpyDeviceToHost, ctx->stream));
     TSR_HIP(hipStreamSynchronize(ctx->stream));
     return TSR_OK;
+}
+
+// ---- Bernoulli-mixture EM on a resident data matrix (bernoulli_mixture.py:108-291) --------
+// E-step: component scores by the bank pass (23-bit MFMA weights), then log marginals and posteriors on the
+// device; the posteriors stay there for the M-step.  `bank` holds, per component k, the one-tap filter
+// log T_k - log(1 - T_k) with c_k = sum_d log(1 - T_k[d]) (the data points are one-frame utterances).
+TSR_API int tsr_mixture_e_step(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, const double *log_weights,
+                               int32_t hard_assignment, double *loglikelihood, float *affinities)
+{
+    TSR_REQUIRE(ctx && bank && cp && log_weights && loglikelihood, "tsr_mixture_e_step: null pointer");
+    TSR_REQUIRE(bank->Lmax == 1, "tsr_mixture_e_step: mixture components are one-tap filters (Lmax=%d)", bank->Lmax);
+    const int64_t P = cp->P;
+    const int K = bank->M;
+    *loglikelihood = 0.0;
+    cp->aff_K = K;
+    cp->aff_colsum.assign((size_t)K, 0.0);
+    if (P == 0) return TSR_OK;
+    TSR_HIP(hipSetDevice(ctx->device));
+    if ((int64_t)P * K > cp->aff_cap) {
+        TSR_HIP(hipStreamSynchronize(ctx->stream));
+        dev_free(cp->d_aff);
+        cp->d_aff = nullptr;
+        cp->aff_cap = 0;
+        TSR_HIP(hipMalloc(reinterpret_cast<void **>(&cp->d_aff), (size_t)P * K * sizeof(float)));
+        cp->aff_cap = (int64_t)P * K;
+    }
+    void *d_all = nullptr, *d_lw = nullptr, *d_blk = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_OUT, (size_t)K * P * sizeof(float), &d_all));
+    TSR_TRY(corpus_score_impl(ctx, bank, cp, TSR_FAST | TSR_W24, (float *)d_all));
+    const int blocks = (int)((P + 255) / 256);
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX, (size_t)K * 8, &d_lw));
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX2, (size_t)blocks * (K + 1) * 8, &d_blk));
+    TSR_HIP(hipMemcpyAsync(d_lw, log_weights, (size_t)K * 8, hipMemcpyHostToDevice, ctx->stream));
+    int nb = 0;
+    TSR_TRY(tsr_launch_mixture_estep(ctx, (const float *)d_all, P, K, (const double *)d_lw, hard_assignment ? 1 : 0, cp->d_aff,
+                                     (double *)d_blk, &nb));
+    std::vector<double> blk((size_t)nb * (K + 1));
+    TSR_HIP(hipMemcpyAsync(blk.data(), d_blk, blk.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    double ll = 0.0;
+    for (int b = 0; b < nb; ++b) {  // block order: reproducible
+        ll += blk[(size_t)b * (K + 1)];
+        for (int k = 0; k < K; ++k) cp->aff_colsum[(size_t)k] += blk[(size_t)b * (K + 1) + 1 + k];
+    }
+    *loglikelihood = ll;
+    if (affinities) TSR_TRY(tsr_download(ctx, affinities, cp->d_aff, (size_t)P * K * sizeof(float)));
+    return TSR_OK;
+}
+
+// M-step sums from the posteriors the latest tsr_mixture_e_step left on the device: weights[k] = mean_n a[n,k]
+// (:175) and sums[k, d] = sum_n a[n,k] x[n,d] (:179; the caller divides and clips as the reference does).
+TSR_API int tsr_mixture_m_step(tsr_ctx *ctx, tsr_corpus *cp, double *weights, float *sums)
+{
+    TSR_REQUIRE(ctx && cp && weights && sums, "tsr_mixture_m_step: null pointer");
+    TSR_REQUIRE(cp->aff_K >= 1 && (cp->P == 0 || cp->d_aff), "tsr_mixture_m_step: no E-step has run on this data matrix");
+    const int64_t P = cp->P, D = cp->D, K = cp->aff_K;
+    for (int64_t k = 0; k < K; ++k) weights[k] = P ? cp->aff_colsum[(size_t)k] / (double)P : 0.0;
+    if (P == 0) {
+        memset(sums, 0, (size_t)(K * D) * sizeof(float));
+        return TSR_OK;
+    }
+    TSR_HIP(hipSetDevice(ctx->device));
+    const int S = (int)std::max<int64_t>(1, std::min<int64_t>(64, P / 64));
+    void *dP = nullptr, *dO = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_RAW, (size_t)S * K * D * 4, &dP));
+    TSR_TRY(tsr_scratch(ctx, SLOT_OUT, (size_t)(K * D) * 4, &dO));
+    TSR_TRY(tsr_launch_mstep(ctx, cp->d_feats, P, (int)D, cp->Dp, cp->d_aff, (int)K, (float *)dP, S, (float *)dO));
+    TSR_HIP(hipMemcpyAsync(sums, dO, (size_t)(K * D) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    return TSR_OK;
+}
+
+TSR_API int tsr_corpus_download_affinities(tsr_ctx *ctx, const tsr_corpus *cp, float *affinities)
+{
+    TSR_REQUIRE(ctx && cp && affinities, "tsr_corpus_download_affinities: null pointer");
+    TSR_REQUIRE(cp->aff_K >= 1 && (cp->P == 0 || cp->d_aff), "tsr_corpus_download_affinities: no E-step has run on this data matrix");
+    if (cp->P == 0) return TSR_OK;
+    TSR_HIP(hipSetDevice(ctx->device));
+    return tsr_download(ctx, affinities, cp->d_aff, (size_t)cp->P * cp->aff_K * sizeof(float));
 }
 
 // ---- single-utterance drop-ins ----------------------------------------------------

@@ -119,6 +119,10 @@ struct tsr_corpus {
     int plan_key = 0;                // (segments, Lmax) the plan was built for
     int plan_nseg = 0;
     int32_t *d_plan = nullptr;       // [3][nseg]: first output, end of outputs, end of rows
+    // Bernoulli mixture: the posterior component probabilities the latest E-step left on the device
+    float *d_aff = nullptr;          // [P][aff_K]
+    int64_t aff_K = 0, aff_cap = 0;  // columns in use; capacity in floats
+    std::vector<double> aff_colsum;  // [aff_K] column sums of d_aff (the M-step's weights x P)
 };
 
 struct tsr_parts {
@@ -172,6 +176,8 @@ int tsr_launch_window_peak_max(tsr_ctx *ctx, const float *d_v, const int64_t *d_
                                const int64_t *d_starts, const int64_t *d_ends, int64_t W, float *d_out);
 int tsr_launch_mstep(tsr_ctx *ctx, const uint8_t *d_X, int64_t P, int D, int Dp, const float *d_aff, int K,
                      float *d_part, int S, float *d_out);
+int tsr_launch_mixture_estep(tsr_ctx *ctx, const float *d_scores, int64_t P, int K, const double *d_log_w, int hard,
+                             float *d_aff, double *d_blk, int *n_blocks);
 int tsr_launch_link_partition(tsr_ctx *ctx, const int32_t *d_times, const int32_t *d_lengths, int64_t n, uint8_t *d_part);
 int tsr_launch_cluster_times(tsr_ctx *ctx, const int32_t *d_times, const int64_t *d_offsets, const int64_t *d_counts, int64_t N,
                              float C0, float C1, const int32_t *d_lens, uint8_t *d_part, int64_t *d_n_clusters,

@@ -54,6 +54,9 @@ SIGNATURES = {
     "tsr_window_peak_max": [_p, _p, _p, _p, _i64, _p, _p, _p, _i64, _p],
     "tsr_edge_corpus_create": [_p, _p, _p, _i64, _i64, _int, _int, C.c_double, _p, _pp],
     "tsr_corpus_weighted_sums": [_p, _p, _p, _i64, _p],
+    "tsr_mixture_e_step": [_p, _p, _p, _p, _i32, C.POINTER(C.c_double), _p],
+    "tsr_mixture_m_step": [_p, _p, _p, _p],
+    "tsr_corpus_download_affinities": [_p, _p, _p],
     "tsr_parts_create": [_p, _p, _p, _i64, _i64, _i64, _i64, _pp],
     "tsr_parts_destroy": [_p],
     "tsr_parts_set_mode": [_p, _int],

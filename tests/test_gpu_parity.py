@@ -909,15 +909,30 @@ def test_bernoulli_mixture_e_step_and_em(mods, oracle):
     found = mix.templates.reshape(Kmix, -1)
     cost = np.abs(found[:, None, :] - protos.reshape(Kmix, -1)[None, :, :]).mean(2)
     assert sorted(cost.argmin(1).tolist()) == list(range(Kmix)) and cost.min(1).max() < 0.08
-    # a deterministic f64 EM from the same start follows the same likelihood path
-    ref = bm.BernoulliMixture(Kmix, data, min_probability=0.05)
-    ref.get_template_loglikelihoods = lambda: oracle.template_loglikelihoods(ref.data_mat, ref.log_templates, ref.log_invtemplates)
-    class _HostSums:                                                   # ... and a NumPy M-step product
-        def weighted_sums(self, w):
-            return (np.asarray(w, np.float64).T @ ref.data_mat.astype(np.float64)).astype(np.float32)
-    ref._corpus = _HostSums()
-    final_ref = ref.run_EM(1e-6, min_probability=0.05, max_iter=40, min_iter=5)
-    assert abs(final - final_ref) <= 1e-4 * abs(final_ref)
+    # a deterministic f64 EM from the same start (oracle E-step, NumPy M-step) follows the same likelihood path
+    start = bm.BernoulliMixture(Kmix, data, min_probability=0.05)
+    X = start.data_mat.astype(np.float64)
+    lt, lit, w = start.log_templates, start.log_invtemplates, start.weights.astype(np.float64)
+    cur, _aff = oracle.mixture_e_step(start.data_mat, lt, lit, w)
+    prev, it = cur / (1 - 1e-6) - 10, 0
+    while it < 5 or (it < 40 and abs((prev - cur) / prev) > 1e-6):
+        prev = cur
+        w = _aff.astype(np.float64).mean(0)
+        T = np.clip(_aff.astype(np.float64).T @ X / N / w[:, None], 0.05, 0.95)
+        lt, lit = np.log(T), np.log(1 - T)
+        cur, _aff = oracle.mixture_e_step(start.data_mat, lt, lit, w)
+        it += 1
+    assert abs(final - prev) <= 1e-4 * abs(prev) and abs(it - mix.iterations) <= 2
+    # posteriors assigned from outside are used by the next M-step (upload path), hard assignment is one-hot
+    mix2 = bm.BernoulliMixture(Kmix, data, min_probability=0.05)
+    mix2.hard_assignment = True
+    mix2._compute_loglikelihoods()
+    hard = mix2.affinities
+    assert set(np.unique(hard)) <= {0.0, 1.0} and np.all(hard.sum(1) == 1)
+    assert np.array_equal(hard.argmax(1), oracle.template_loglikelihoods(mix2.data_mat, mix2.log_templates, mix2.log_invtemplates).argmax(1))
+    mix2.affinities = aff_ref
+    mix2.M_step()
+    assert np.allclose(mix2.weights, aff_ref.mean(0), atol=1e-6)
 
 
 def test_g21_bernoulli_mixture_from_the_references_own_code(mods):

@@ -1,6 +1,8 @@
 import sys, numpy as np
 d = np.loadtxt(sys.argv[1])
 names = ["first half (steps 0..H-1)", "dma wait", "barrier", "dma issue", "second half + combine", "between iterations"]
+if len(sys.argv) > 2 and sys.argv[2] == "alt":
+    names = ["C: MFMAs", "barrier behind C", "O: emission", "O: DMA wait", "O: finishing+DMA+priming", "barrier behind O"]
 tot = d[:, 2:].sum(1)
 print("waves %d, mean stamped cycles per wave %.0f (s_memtime ticks)" % (len(d), tot.mean()))
 for i, n in enumerate(names):
