@@ -290,6 +290,34 @@ int tsr_window_peak_max(tsr_ctx *ctx, const tsr_corpus *corpus, const float *val
 int tsr_edge_corpus_create(tsr_ctx *ctx, const double *S_cat, const int64_t *frame_offsets, int64_t N,
                            int64_t H, int block_length, int spread_length, double quantile,
                            const double *abst_threshold, tsr_corpus **out);
+/* The magnitude_thresholded_edges branch (get_train_data.py:2528-2546): as above, with the edge strengths
+ * zeroed wherever mask_cat u8 [sum T_n, H] (time-major like S_cat) is 0, before the thresholding. */
+int tsr_edge_corpus_create_masked(tsr_ctx *ctx, const double *S_cat, const uint8_t *mask_cat, const int64_t *frame_offsets,
+                                  int64_t N, int64_t H, int block_length, int spread_length, double quantile,
+                                  const double *abst_threshold, tsr_corpus **out);
+/* threshold_edgemap (edge_signal_proc.py:1184-1252, critical_bands=None) over threshold_edge_block
+ * (:1257-1307): every row block [row_breaks[b], row_breaks[b+1]) of E f64 [rows, T], in place: the
+ * int(quantile * n)-th of its n sorted positive values is the quantile; entries that are positive and
+ * >= max(quantile value, abst_threshold[b]) become 1 (or keep their value when convert_to_binary == 0),
+ * everything else 0; a block without positive values becomes 0.  thresholds f64 [n_blocks] (may be NULL)
+ * receives the quantile values (NaN for empty blocks) -- what report_level=True returns.
+ * spread_edgemap (:1397-1404) over _spread_edges (:1406-1417): every row block, in place, becomes the maximum
+ * (floored at 0) over the shifts k * orientations[b] = (rows, columns), k in [-spread_length, spread_length],
+ * zeros outside the block. */
+int tsr_threshold_edgemap(tsr_ctx *ctx, double *E, const int64_t *row_breaks, int32_t n_blocks, int64_t T,
+                          double quantile, const double *abst_threshold, int32_t convert_to_binary, double *thresholds);
+int tsr_spread_edgemap(tsr_ctx *ctx, double *E, const int64_t *row_breaks, int32_t n_blocks, int64_t T,
+                       const int32_t *orientations, int32_t spread_length);
+/* magnitude_features (edge_signal_proc.py:600-670; whole_block == 0) and magnitude_features_whole_block
+ * (:673-747; whole_block != 0): S f64 [F0, T] (frequency x time) -> out u8 [T, F], F = ceil(F0 / down) (F0
+ * when down == 0).  Optional maximum over mag_smooth_freq bins (SciPy's maximum_filter, reflected ends), then
+ * every mag_downsample_freq-th bin; overlapping estimation windows of block_length frames; a cell is set when
+ * its value is >= the window's quantile -- per bin, or one for all bins (whole_block); then an OR over
+ * +-mag_spread_length frames, or (whole_block) the square spread of radius spread_radius with SciPy's
+ * correlate-and-truncate arithmetic. */
+int tsr_magnitude_features(tsr_ctx *ctx, const double *S, int64_t F0, int64_t T, int32_t block_length,
+                           int32_t spread_radius, double quantile, int32_t mag_smooth_freq, int32_t mag_downsample_freq,
+                           int32_t mag_spread_length, int32_t whole_block, uint8_t *out);
 
 /* M-step sums of the Bernoulli mixture (bernoulli_mixture.py:179, np.dot(affinities.T, data_mat)) on a
  * resident binary corpus: out f32 [K, D], out[k][d] = sum_p weights[p][k] * x[p][d], weights f32 [P, K]

@@ -507,6 +507,191 @@ def get_edge_features(S, block_length=40, spread_length=1, threshold=.7, abst_th
     return reorg_part_for_fast_filtering(E).astype(np.uint8)
 
 
+# ---- the rest of SURVEY 8(f) N3: whole-array thresholding / spreading and the magnitude branches ----------
+def threshold_edgemap(E, quantile_level, edge_feature_row_breaks, abst_threshold=ABST_THRESHOLD, convert_to_binary=True):
+    """edge_signal_proc.py:1184-1252 with critical_bands=None: every row block [breaks[i-1], breaks[i]) of E
+    (all columns) through threshold_edge_block (:1257-1307), in place.  Returns the blocks' quantile values
+    (what report_level=True hands back; nan for a block without positive values)."""
+    taus = np.full(len(edge_feature_row_breaks) - 1, np.nan)
+    for i in range(1, len(edge_feature_row_breaks)):
+        B = E[int(edge_feature_row_breaks[i - 1]):int(edge_feature_row_breaks[i]), :]
+        pos = B > 0
+        vals = np.sort(B[pos].ravel())
+        if vals.shape[0] <= 0:
+            B[:] = 0
+            continue
+        tau = vals[int(quantile_level * vals.shape[0])]
+        taus[i - 1] = tau
+        sig = pos & (B >= max(tau, abst_threshold[i - 1]))
+        B[:] = np.where(sig, 1.0 if convert_to_binary else B, 0.0)
+    return taus
+
+
+def spread_edgemap(T, edge_feature_row_breaks, edge_orientation, spread_length=3):
+    """edge_signal_proc.py:1397-1404: _spread_edges on every row block along its own orientation, in place."""
+    for i in range(1, len(edge_feature_row_breaks)):
+        a, b = int(edge_feature_row_breaks[i - 1]), int(edge_feature_row_breaks[i])
+        T[a:b, :] = _spread_edges(T[a:b], [int(x) for x in edge_orientation[i - 1]], spread_length)
+
+
+def _max_filter_freq(S, size):
+    """scipy.ndimage.maximum_filter(S, (size, 1)) (mode 'reflect', origin 0) without SciPy: output row i is the
+    maximum of rows i - size//2 ... i - size//2 + size - 1, indices reflected at the ends (d c b a | a b c d | ...)."""
+    H = S.shape[0]
+    lo = size // 2
+    idx = np.arange(-lo, H - lo + size - 1)
+    period = 2 * H
+    idx = np.mod(idx, period)
+    idx = np.where(idx >= H, period - 1 - idx, idx)
+    P = S[idx]
+    return np.max(np.stack([P[j:j + H] for j in range(size)]), axis=0)
+
+
+def _magnitude_windows(num_frames, block_length):
+    """The (estimation window, frames it sets, nominal window length of the rank rule) triples of
+    edge_signal_proc.py:648-666 / :720-738."""
+    bq = block_length // 4
+    wins = [(0, min(3 * bq, num_frames), 0, min(2 * bq, num_frames), None)]   # first: rank int(q * 3 bq [* F] + .5)
+    nxt = 2 * bq
+    while nxt < num_frames:
+        a = nxt - bq
+        b = min(num_frames, a + 4 * bq)
+        last = min(nxt + 2 * bq, num_frames)
+        wins.append((a, b, nxt, last, b - a))
+        nxt = last
+    return bq, wins
+
+
+def magnitude_features(S, block_length, spread_radius, threshold_quantile, mag_smooth_freq, mag_downsample_freq,
+                       mag_spread_length=1):
+    """edge_signal_proc.py:600-670: S [F, T] -> uint8 [T, F'], per frequency bin the frames at or above the
+    bin's own quantile inside overlapping windows, then an OR over +-mag_spread_length frames."""
+    S = np.asarray(S, np.float64)
+    if mag_smooth_freq > 0:
+        S = _max_filter_freq(S, mag_smooth_freq)
+    if mag_downsample_freq > 0:
+        S = S[::mag_downsample_freq]
+    S = S.T
+    T = S.shape[0]
+    E = np.zeros(S.shape, np.uint8)
+    bq, wins = _magnitude_windows(T, block_length)
+    for a, b, s0, s1, n in wins:
+        block = np.sort(S[a:b], axis=0)
+        k = int(threshold_quantile * 3 * bq + .5) if n is None else int(threshold_quantile * n)
+        E[s0:s1] = S[s0:s1] >= block[k]
+    m = mag_spread_length
+    if m > 0:
+        Z = np.zeros((T + 2 * m, E.shape[1]), np.uint8)
+        Z[m:m + T] = E
+        E = np.max(np.stack([Z[j:j + T] for j in range(2 * m + 1)]), axis=0).astype(np.uint8)
+    return E
+
+
+def whole_block_spread_min_count(spread_radius):
+    """magnitude_features_whole_block's spread (:741-744) is correlate(E, w) >= 1 with w = 1/r everywhere and 1
+    in the centre, E uint8: SciPy accumulates the products in double and casts the sum to uint8 (truncation), so
+    a frame/bin with a clear centre is set iff the n-fold repeated addition of fl(1/r) reaches 1.0.  Returns the
+    smallest such n (the sum is non-decreasing in n)."""
+    x, s, n = 1.0 / spread_radius, 0.0, 0
+    while s < 1.0:
+        s += x
+        n += 1
+    return n
+
+
+def magnitude_features_whole_block(S, block_length, spread_radius, threshold_quantile, mag_smooth_freq,
+                                   mag_downsample_freq):
+    """edge_signal_proc.py:673-747: as magnitude_features with ONE quantile per window over all bins, and a
+    square spread: a cell is set if it was set or at least `whole_block_spread_min_count` of the other cells of
+    its (2r+1)^2 neighbourhood were."""
+    S = np.asarray(S, np.float64)
+    if mag_smooth_freq > 0:
+        S = _max_filter_freq(S, mag_smooth_freq)
+    if mag_downsample_freq > 0:
+        S = S[::mag_downsample_freq]
+    S = S.T
+    T, F = S.shape
+    E = np.zeros(S.shape, np.uint8)
+    bq, wins = _magnitude_windows(T, block_length)
+    for a, b, s0, s1, n in wins:
+        block = np.sort(S[a:b].ravel())
+        k = int(threshold_quantile * 3 * bq * F + .5) if n is None else int(threshold_quantile * n * F)
+        E[s0:s1] = S[s0:s1] >= block[k]
+    r = spread_radius
+    if r > 0:
+        Z = np.zeros((T + 2 * r, F + 2 * r), np.int64)
+        Z[r:r + T, r:r + F] = E
+        box = sum(Z[i:i + T, j:j + F] for i in range(2 * r + 1) for j in range(2 * r + 1))
+        E = ((E > 0) | (box - E >= whole_block_spread_min_count(r))).astype(np.uint8)
+    return E.astype(np.uint8)
+
+
+def get_edge_features_with_parameters(S, p):
+    """get_train_data.py:2489-2557 with its branches; `p` carries the EdgemapParameters fields.  The
+    `magnitude_features` branch is dead in the reference (it calls esp.magnitude_features with one positional
+    argument too few, :2494-2498) and is not restated."""
+    S = np.asarray(S, np.float64)
+    if p.auxiliary_data:
+        A, S = S[-3:], S[:-3]
+    if p.magnitude_and_edge_features:
+        E2 = magnitude_features_whole_block(S.copy(), p.magnitude_block_length, p.magnitude_spread,
+                                            p.magnitude_threshold, p.mag_smooth_freq, p.mag_downsample_freq)
+        E = edge_map_no_threshold(S)
+        edge_map_threshold_segments(E, p.block_length, p.spread_length, p.threshold)   # (default abst_threshold, :2509-2515)
+        if not p.auxiliary_data:
+            return np.hstack((E.T, E2))
+        AB = magnitude_features(A, p.magnitude_block_length, 0, p.auxiliary_threshold, 0, 0, mag_spread_length=1)
+        return np.hstack((E.T, E2, AB))
+    if p.magnitude_thresholded_edges:
+        E2 = magnitude_features_whole_block(S.copy(), p.magnitude_block_length, p.magnitude_spread,
+                                            p.magnitude_threshold, p.mag_smooth_freq, p.mag_downsample_freq)
+        E = edge_map_no_threshold(S)
+        E2 = E2[::-1].T                                  # (the reference reverses the TIME axis here, :2537)
+        for i in range(8):
+            E[E2.shape[0] * i:E2.shape[0] * (i + 1)] *= E2
+        edge_map_threshold_segments(E, p.block_length, p.spread_length, p.threshold, p.abst_threshold)
+        return reorg_part_for_fast_filtering(E)
+    E = edge_map_no_threshold(S)
+    edge_map_threshold_segments(E, p.block_length, p.spread_length, p.threshold, p.abst_threshold)
+    return reorg_part_for_fast_filtering(E)
+
+
+GAUSSIAN5BY5 = np.array([[0.19785663, 0.36326131, 0.44481078, 0.36326131, 0.19785663],
+                         [0.36326131, 0.66694134, 0.81666476, 0.66694134, 0.36326131],
+                         [0.44481078, 0.81666476, 1., 0.81666476, 0.44481078],
+                         [0.36326131, 0.66694134, 0.81666476, 0.66694134, 0.36326131],
+                         [0.19785663, 0.36326131, 0.44481078, 0.36326131, 0.19785663]], dtype=np.float32)
+
+
+def gaussian_edge_count(E_edges):
+    """get_train_data.py:2592-2598: scipy.signal.convolve(E_edges, tile(gaussian5by5, 8 edges), 'same')[:, :, 4]:
+    with the same 5x5 weights for every edge type this is the Gaussian-weighted number of edges around (t, f),
+    zeros outside.  f64 sums here; the reference's are float32 (direct) or FFT-based, equal to ~1e-6."""
+    cnt = np.asarray(E_edges, np.float64).sum(2)
+    T, F = cnt.shape
+    Z = np.zeros((T + 4, F + 4))
+    Z[2:2 + T, 2:2 + F] = cnt
+    g = GAUSSIAN5BY5.astype(np.float64)
+    return sum(g[i, j] * Z[4 - i:4 - i + T, 4 - j:4 - j + F] for i in range(5) for j in range(5))
+
+
+def get_part_features_mag_aux(E, p):
+    """get_train_data.py:2577-2614, the mag_data and auxiliary_data branch: E [T, 8 F + mags + aux] ->
+    spread part map [T, F - 4, numParts] (zero rows appended up to T frames)."""
+    E = np.asarray(E).T.astype(np.uint8)
+    nm, na = p.num_mag_channels, p.num_auxiliary_data
+    E_edges, E_mags, E_aux = E[:-nm - na].T, E[-nm - na:-na].T, E[-na:].T
+    F = E_edges.shape[1] // 8
+    E_edges = E_edges.reshape(len(E_edges), F, 8)
+    mask = (gaussian_edge_count(E_edges) > 12).astype(np.uint8)
+    out = code_parts_mag_aux(E_edges, E_mags, E_aux, p.logParts, p.logInvParts, p.logMagFeatures, p.logInvMagFeatures,
+                             p.logAuxiliaryFeatures, p.logInvAuxiliaryFeatures, mask)
+    spread = spread_patches(argmax_last(out), p.spreadRadiusX, p.spreadRadiusY, p.numParts)
+    if len(spread) < E.shape[1]:
+        spread = np.vstack((spread, np.zeros((E.shape[1] - len(spread),) + spread.shape[1:])))
+    return spread
+
+
 # ---- Bernoulli mixture E-step (SURVEY 8(f) N4), restated from text in f64 (the reference evaluates it with
 # a float32 BLAS product whose summation order is not defined: checks are tolerance-based; golden g21 holds what
 # the reference's own class computes, run through oracle/py2ref.py).

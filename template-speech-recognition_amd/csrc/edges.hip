@@ -25,6 +25,7 @@ constexpr int kThreads = 256;
 
 struct EdgeArgs {
     const double *S;           // [P][H] time-major spectrogram stream
+    const uint8_t *mask;       // [P][H] or null: edge strengths are zeroed where the mask is (get_train_data.py:2536-2539)
     const int64_t *utt_off;    // [N+1]
     const int32_t *item;       // [n_items][4]: utterance, first column of the window, width, first kept column
     int H, spread, Dp, max_w;
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(kThreads) void edge_block_kernel(const EdgeArgs a)
                 hi *= sg;
                 if (d >= lo && d >= hi && d >= 0.0) v = d;
             }
+            if (a.mask && !a.mask[(o + t) * H + h]) v = 0.0;
             vals[idx] = v;
             npos += v > 0.0;
         }
@@ -250,6 +252,7 @@ __global__ __launch_bounds__(512) void edge_block_wave_kernel(const EdgeArgs a)
                 hi *= sg;
                 if (d >= lo && d >= hi && d >= 0.0) x = d;
             }
+            if (a.mask && !a.mask[(o + t) * H + h]) x = 0.0;
         }
         v[i] = x;
         npos += x > 0.0;
@@ -347,13 +350,14 @@ int launch_edge_wave(tsr_ctx *ctx, const EdgeArgs &a, int64_t n_items, size_t ld
 
 }  // namespace
 
-int tsr_launch_edge_blocks(tsr_ctx *ctx, const double *d_S, const int64_t *d_utt_off, const int32_t *d_items,
+int tsr_launch_edge_blocks(tsr_ctx *ctx, const double *d_S, const uint8_t *d_mask, const int64_t *d_utt_off, const int32_t *d_items,
                            int64_t n_items, int H, int block_length, int spread, double q, const double *abst,
                            int Dp, uint8_t *d_out)
 {
     if (n_items <= 0) return TSR_OK;
     EdgeArgs a;
     a.S = d_S;
+    a.mask = d_mask;
     a.utt_off = d_utt_off;
     a.item = d_items;
     a.H = H;

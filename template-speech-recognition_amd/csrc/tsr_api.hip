@@ -917,7 +917,7 @@ TSR_API int tsr_window_peak_max(tsr_ctx *ctx, const tsr_corpus *cp, const float 
 // ---- edge front-end ---------------------------------------------------
 // get_edge_features, default branch (get_train_data.py:2547-2557): spectrograms -> a resident binary
 // edge corpus (D = 8 H, layout [frame][h][edge type] = reorg_part_for_fast_filtering).
-TSR_API int tsr_edge_corpus_create(tsr_ctx *ctx, const double *S_cat, const int64_t *frame_offsets, int64_t N,
+static int edge_corpus_create_impl(tsr_ctx *ctx, const double *S_cat, const uint8_t *mask_cat, const int64_t *frame_offsets, int64_t N,
                                    int64_t H, int block_length, int spread_length, double quantile,
                                    const double *abst_threshold, tsr_corpus **out)
 {
@@ -943,8 +943,12 @@ TSR_API int tsr_edge_corpus_create(tsr_ctx *ctx, const double *S_cat, const int6
     TSR_HIP(hipSetDevice(ctx->device));
     tsr_corpus *cp = nullptr;
     TSR_TRY(tsr_corpus_create_empty(ctx, frame_offsets, N, 8 * H, &cp));
-    void *dS = nullptr, *dO = nullptr, *dI = nullptr;
+    void *dS = nullptr, *dO = nullptr, *dI = nullptr, *dM = nullptr;
     int s = tsr_scratch(ctx, SLOT_RAW, (size_t)std::max<int64_t>(P * H, 1) * 8, &dS);
+    if (s == TSR_OK && mask_cat && P > 0) {
+        s = tsr_scratch(ctx, SLOT_IN, (size_t)(P * H), &dM);
+        if (s == TSR_OK && hipMemcpyAsync(dM, mask_cat, (size_t)(P * H), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
+    }
     if (s == TSR_OK) s = tsr_scratch(ctx, SLOT_AUX, (size_t)(N + 1) * 8, &dO);
     if (s == TSR_OK) s = tsr_scratch(ctx, SLOT_W, std::max<size_t>(items.size(), 4) * 4, &dI);
     if (s == TSR_OK && P > 0 &&
@@ -953,7 +957,7 @@ TSR_API int tsr_edge_corpus_create(tsr_ctx *ctx, const double *S_cat, const int6
          hipMemcpyAsync(dI, items.data(), items.size() * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess))
         s = TSR_ERR_HIP;
     if (s == TSR_OK && P > 0)
-        s = tsr_launch_edge_blocks(ctx, (const double *)dS, (const int64_t *)dO, (const int32_t *)dI, (int64_t)(items.size() / 4),
+        s = tsr_launch_edge_blocks(ctx, (const double *)dS, (const uint8_t *)dM, (const int64_t *)dO, (const int32_t *)dI, (int64_t)(items.size() / 4),
                                    (int)H, block_length, spread_length, quantile, abst_threshold, cp->Dp, cp->d_feats);
     if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
     if (s != TSR_OK) {
@@ -963,6 +967,151 @@ TSR_API int tsr_edge_corpus_create(tsr_ctx *ctx, const double *S_cat, const int6
         return s;
     }
     *out = cp;
+    return TSR_OK;
+}
+
+TSR_API int tsr_edge_corpus_create(tsr_ctx *ctx, const double *S_cat, const int64_t *frame_offsets, int64_t N,
+                                   int64_t H, int block_length, int spread_length, double quantile,
+                                   const double *abst_threshold, tsr_corpus **out)
+{
+    return edge_corpus_create_impl(ctx, S_cat, nullptr, frame_offsets, N, H, block_length, spread_length, quantile, abst_threshold, out);
+}
+
+TSR_API int tsr_edge_corpus_create_masked(tsr_ctx *ctx, const double *S_cat, const uint8_t *mask_cat, const int64_t *frame_offsets,
+                                          int64_t N, int64_t H, int block_length, int spread_length, double quantile,
+                                          const double *abst_threshold, tsr_corpus **out)
+{
+    TSR_REQUIRE(mask_cat || (frame_offsets && frame_offsets[N] == 0), "tsr_edge_corpus_create_masked: null mask");
+    return edge_corpus_create_impl(ctx, S_cat, mask_cat, frame_offsets, N, H, block_length, spread_length, quantile, abst_threshold, out);
+}
+
+// ---- whole-array thresholding / spreading of an edge-strength map (edge_signal_proc.py:1184-1307, :1397-1417) ----
+TSR_API int tsr_threshold_edgemap(tsr_ctx *ctx, double *E, const int64_t *row_breaks, int32_t n_blocks, int64_t T,
+                                  double quantile, const double *abst_threshold, int32_t convert_to_binary, double *thresholds)
+{
+    TSR_REQUIRE(ctx && E && row_breaks && abst_threshold, "tsr_threshold_edgemap: null pointer");
+    TSR_REQUIRE(n_blocks >= 0 && n_blocks <= 4096 && T >= 0, "tsr_threshold_edgemap: bad geometry");
+    TSR_REQUIRE(quantile >= 0.0 && quantile < 1.0, "tsr_threshold_edgemap: quantile %g outside [0, 1) (the reference indexes past its sorted values at 1)", quantile);
+    for (int b = 0; b < n_blocks; ++b)
+        TSR_REQUIRE(row_breaks[b] >= 0 && row_breaks[b + 1] >= row_breaks[b], "tsr_threshold_edgemap: row breaks must ascend");
+    if (n_blocks == 0 || T == 0) return TSR_OK;
+    const int64_t rows = row_breaks[n_blocks];
+    TSR_HIP(hipSetDevice(ctx->device));
+    void *dE = nullptr, *dB = nullptr, *dA = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_RAW, (size_t)std::max<int64_t>(rows * T, 1) * 8, &dE));
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX, (size_t)(n_blocks + 1) * 8, &dB));
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX2, (size_t)n_blocks * 16, &dA));  // [abst | taus]
+    TSR_HIP(hipMemcpyAsync(dE, E, (size_t)(rows * T) * 8, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(dB, row_breaks, (size_t)(n_blocks + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(dA, abst_threshold, (size_t)n_blocks * 8, hipMemcpyHostToDevice, ctx->stream));
+    double *d_taus = (double *)dA + n_blocks;
+    TSR_TRY(tsr_launch_threshold_edgemap(ctx, (double *)dE, (const int64_t *)dB, n_blocks, T, quantile, (const double *)dA,
+                                         convert_to_binary ? 1 : 0, d_taus));
+    // only the rows inside [breaks[0], breaks[n]) are touched
+    const int64_t r0 = row_breaks[0];
+    TSR_HIP(hipMemcpyAsync(E + r0 * T, (double *)dE + r0 * T, (size_t)((rows - r0) * T) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (thresholds) TSR_HIP(hipMemcpyAsync(thresholds, d_taus, (size_t)n_blocks * 8, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    return TSR_OK;
+}
+
+TSR_API int tsr_spread_edgemap(tsr_ctx *ctx, double *E, const int64_t *row_breaks, int32_t n_blocks, int64_t T,
+                               const int32_t *orientations, int32_t spread_length)
+{
+    TSR_REQUIRE(ctx && E && row_breaks && orientations, "tsr_spread_edgemap: null pointer");
+    TSR_REQUIRE(n_blocks >= 0 && n_blocks <= 4096 && T >= 0, "tsr_spread_edgemap: bad geometry");
+    TSR_REQUIRE(spread_length >= 1, "tsr_spread_edgemap: spread_length must be >= 1 (the reference's zero-padded copy is empty at 0)");
+    for (int b = 0; b < n_blocks; ++b)
+        TSR_REQUIRE(row_breaks[b] >= 0 && row_breaks[b + 1] >= row_breaks[b], "tsr_spread_edgemap: row breaks must ascend");
+    if (n_blocks == 0 || T == 0) return TSR_OK;
+    const int64_t rows = row_breaks[n_blocks];
+    TSR_HIP(hipSetDevice(ctx->device));
+    void *dE = nullptr, *dO = nullptr, *dB = nullptr, *dD = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_RAW, (size_t)std::max<int64_t>(rows * T, 1) * 8, &dE));
+    TSR_TRY(tsr_scratch(ctx, SLOT_OUT, (size_t)std::max<int64_t>(rows * T, 1) * 8, &dO));
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX, (size_t)(n_blocks + 1) * 8, &dB));
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX2, (size_t)n_blocks * 8, &dD));
+    TSR_HIP(hipMemcpyAsync(dE, E, (size_t)(rows * T) * 8, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(dB, row_breaks, (size_t)(n_blocks + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(dD, orientations, (size_t)n_blocks * 8, hipMemcpyHostToDevice, ctx->stream));
+    TSR_TRY(tsr_launch_spread_edgemap(ctx, (const double *)dE, (double *)dO, (const int64_t *)dB, n_blocks, rows, T,
+                                      (const int32_t *)dD, spread_length));
+    const int64_t r0 = row_breaks[0];
+    TSR_HIP(hipMemcpyAsync(E + r0 * T, (double *)dO + r0 * T, (size_t)((rows - r0) * T) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    return TSR_OK;
+}
+
+// ---- magnitude features (edge_signal_proc.py:600-747) ------------------------------------------------------------
+namespace {
+struct MagWinHost {  // mirrors edges2.hip's MagWin
+    int a, b, s0, s1;
+    long long k;
+};
+}  // namespace
+
+TSR_API int tsr_magnitude_features(tsr_ctx *ctx, const double *S, int64_t F0, int64_t T, int32_t block_length,
+                                   int32_t spread_radius, double quantile, int32_t mag_smooth_freq, int32_t mag_downsample_freq,
+                                   int32_t mag_spread_length, int32_t whole_block, uint8_t *out)
+{
+    TSR_REQUIRE(ctx && S && out, "tsr_magnitude_features: null pointer");
+    TSR_REQUIRE(F0 >= 1 && F0 <= 65536 && T >= 1 && T < ((int64_t)1 << 30), "tsr_magnitude_features: bad shape [%lld, %lld]", (long long)F0, (long long)T);
+    TSR_REQUIRE(block_length >= 4, "tsr_magnitude_features: block_length %d < 4 (the reference's window never advances)", block_length);
+    TSR_REQUIRE(mag_smooth_freq >= 0 && mag_downsample_freq >= 0 && mag_spread_length >= 0 && spread_radius >= 0 && spread_radius <= 64,
+                "tsr_magnitude_features: negative or oversized parameter");
+    TSR_REQUIRE(quantile >= 0.0, "tsr_magnitude_features: negative quantile");
+    const int down = mag_downsample_freq;
+    const int64_t F = down > 0 ? (F0 + down - 1) / down : F0;
+    const int bq = block_length / 4;
+    // the estimation windows and the frames they set (:648-666 / :720-738); ranks beyond a window's sorted
+    // values are an IndexError in the reference
+    std::vector<MagWinHost> wins;
+    const int64_t per = whole_block ? F : 1;
+    {
+        MagWinHost w;
+        w.a = 0;
+        w.b = (int)std::min<int64_t>(3 * bq, T);
+        w.s0 = 0;
+        w.s1 = (int)std::min<int64_t>(2 * bq, T);
+        w.k = (long long)(quantile * 3 * bq * (double)per + .5);
+        wins.push_back(w);
+        int64_t next = 2 * bq;
+        while (next < T) {
+            w.a = (int)(next - bq);
+            w.b = (int)std::min<int64_t>(T, (int64_t)w.a + 4 * bq);
+            w.s0 = (int)next;
+            w.s1 = (int)std::min<int64_t>(next + 2 * bq, T);
+            w.k = (long long)(quantile * (double)(w.b - w.a) * (double)per);
+            wins.push_back(w);
+            next = w.s1;
+        }
+    }
+    for (const MagWinHost &w : wins)
+        TSR_REQUIRE(w.k >= 0 && w.k < (long long)(w.b - w.a) * per,
+                    "tsr_magnitude_features: rank %lld outside a window of %lld values (IndexError in the reference)", w.k,
+                    (long long)(w.b - w.a) * per);
+    int min_count = 0;
+    if (whole_block && spread_radius > 0) {  // correlate(E, w) >= 1 with E uint8: the n-fold repeated sum of fl(1/r) reaches 1.0
+        const double x = 1.0 / spread_radius;
+        double acc = 0.0;
+        while (acc < 1.0) {
+            acc += x;
+            ++min_count;
+        }
+    }
+    TSR_HIP(hipSetDevice(ctx->device));
+    void *dS = nullptr, *dS2 = nullptr, *dW = nullptr, *dE = nullptr, *dO = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_RAW, (size_t)(F0 * T) * 8, &dS));
+    TSR_TRY(tsr_scratch(ctx, SLOT_OUT, (size_t)(F * T) * 8, &dS2));
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX, wins.size() * sizeof(MagWinHost), &dW));
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX2, (size_t)(F * T), &dE));
+    TSR_TRY(tsr_scratch(ctx, SLOT_IN, (size_t)(F * T), &dO));
+    TSR_HIP(hipMemcpyAsync(dS, S, (size_t)(F0 * T) * 8, hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(dW, wins.data(), wins.size() * sizeof(MagWinHost), hipMemcpyHostToDevice, ctx->stream));
+    TSR_TRY(tsr_launch_magnitude(ctx, (const double *)dS, (int)F0, T, mag_smooth_freq, down, (int)F, (double *)dS2, dW, (int)wins.size(),
+                                 whole_block ? 1 : 0, mag_spread_length, spread_radius, min_count, (uint8_t *)dE, (uint8_t *)dO));
+    TSR_HIP(hipMemcpyAsync(out, dO, (size_t)(F * T), hipMemcpyDeviceToHost, ctx->stream));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
     return TSR_OK;
 }
 

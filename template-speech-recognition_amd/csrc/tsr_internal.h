@@ -183,9 +183,16 @@ int tsr_launch_cluster_times(tsr_ctx *ctx, const int32_t *d_times, const int64_t
                              float C0, float C1, const int32_t *d_lens, uint8_t *d_part, int64_t *d_n_clusters,
                              int32_t *d_starts, int32_t *d_ends);
 // edges.hip
-int tsr_launch_edge_blocks(tsr_ctx *ctx, const double *d_S, const int64_t *d_utt_off, const int32_t *d_items,
+int tsr_launch_edge_blocks(tsr_ctx *ctx, const double *d_S, const uint8_t *d_mask, const int64_t *d_utt_off, const int32_t *d_items,
                            int64_t n_items, int H, int block_length, int spread, double q, const double *abst,
                            int Dp, uint8_t *d_out);
+// edges2.hip
+int tsr_launch_threshold_edgemap(tsr_ctx *ctx, double *d_E, const int64_t *d_breaks, int nb, int64_t T, double q,
+                                 const double *d_abst, int binary, double *d_taus);
+int tsr_launch_spread_edgemap(tsr_ctx *ctx, const double *d_in, double *d_out, const int64_t *d_breaks, int nb, int64_t rows,
+                              int64_t T, const int32_t *d_orient, int spread);
+int tsr_launch_magnitude(tsr_ctx *ctx, const double *d_S, int F0, int64_t T, int smooth, int down, int F, double *d_S2,
+                         const void *d_wins, int n_wins, int whole, int m, int r, int min_count, uint8_t *d_E, uint8_t *d_out);
 // parts_mfma.hip
 int tsr_parts_mfma_prepare(tsr_ctx *ctx, tsr_parts *p, const double *lp, const double *lip);
 void tsr_parts_mfma_free(tsr_parts *p);

@@ -23,6 +23,7 @@ from tsr_hip import api
 from . import code_parts as cp
 from . import compute_likelihood_linear_filter
 from . import spread_waliji_patches as swp
+from . import edge_signal_proc as esp
 
 
 def reorg_part_for_fast_filtering(part, feature_types=8):
@@ -70,14 +71,60 @@ def get_part_features(E, parameters, verbose=False):
     (logParts, logInvParts, bernsteinEdgeThreshold, spreadRadiusX, spreadRadiusY,
     numParts, partGraph; :2203-2473)."""
     if getattr(parameters, "mag_data", False) and getattr(parameters, "auxiliary_data", False):
-        raise NotImplementedError("the magnitude/auxiliary-channel coder (code_parts_mag_aux) is "
-                                  "not part of the accelerated path")
+        return _get_part_features_mag_aux(E, parameters)
     parts = _device_parts(parameters.logParts, parameters.logInvParts)
     if int(parameters.numParts) != parts.K:
         raise ValueError("numParts=%d but logParts holds %d parts" % (parameters.numParts, parts.K))
     return parts.features(np.asarray(E).astype(np.uint8), parameters.bernsteinEdgeThreshold,
                           spread=(parameters.spreadRadiusX, parameters.spreadRadiusY),
                           graph=getattr(parameters, "partGraph", None))
+
+
+gaussian5by5 = np.array([[0.19785663, 0.36326131, 0.44481078, 0.36326131, 0.19785663],
+                         [0.36326131, 0.66694134, 0.81666476, 0.66694134, 0.36326131],
+                         [0.44481078, 0.81666476, 1., 0.81666476, 0.44481078],
+                         [0.36326131, 0.66694134, 0.81666476, 0.66694134, 0.36326131],
+                         [0.19785663, 0.36326131, 0.44481078, 0.36326131, 0.19785663]], dtype=np.float32)
+
+
+def _gaussian_edge_count(E_edges):
+    """The reference's `convolve(E_edges, tile(gaussian5by5, 8 edge types), mode='same')[:, :, 4]` (:2592-2598):
+    the same 5x5 weights apply to every edge type, so this is the Gaussian-weighted count of the edges around
+    (t, f), zeros outside (float64 sums of 25 shifted planes)."""
+    cnt = np.asarray(E_edges, np.float64).sum(2)
+    T, F = cnt.shape
+    Z = np.zeros((T + 4, F + 4))
+    Z[2:2 + T, 2:2 + F] = cnt
+    g = gaussian5by5.astype(np.float64)
+    out = np.zeros((T, F))
+    for i in range(5):
+        for j in range(5):
+            out += g[i, j] * Z[4 - i:4 - i + T, 4 - j:4 - j + F]
+    return out
+
+
+def _get_part_features_mag_aux(E, parameters):
+    """The mag_data + auxiliary_data branch of get_part_features (:2577-2614): E [T, 8 F + mag channels +
+    auxiliary channels] -> Gaussian edge-count mask (> 12) -> code_parts_mag_aux -> argmax -> spread_patches,
+    zero rows appended up to T frames."""
+    E = np.asarray(E).T.astype(np.uint8)
+    nm, na = int(parameters.num_mag_channels), int(parameters.num_auxiliary_data)
+    E_edges, E_mags, E_aux = E[:-nm - na].T, E[-nm - na:-na].T, E[-na:].T
+    num_edges = 8
+    F = E_edges.shape[1] // num_edges
+    E_edges = np.ascontiguousarray(E_edges).reshape(len(E_edges), F, num_edges)
+    if tuple(np.shape(parameters.logParts)[1:3]) != (5, 5):
+        raise NotImplementedError("get_part_features: the reference's non-5x5 Gaussian uses an undefined name (part_freq)")
+    mask = (_gaussian_edge_count(E_edges) > 12).astype(np.uint8)
+    out = cp.code_parts_mag_aux(E_edges, np.ascontiguousarray(E_mags), np.ascontiguousarray(E_aux), parameters.logParts,
+                                parameters.logInvParts, parameters.logMagFeatures, parameters.logInvMagFeatures,
+                                parameters.logAuxiliaryFeatures, parameters.logInvAuxiliaryFeatures, mask)
+    max_responses = np.argmax(out, -1)
+    spread = cp.spread_patches(max_responses, parameters.spreadRadiusX, parameters.spreadRadiusY, parameters.numParts)
+    missing = E.shape[1] - len(spread)
+    if missing > 0:
+        spread = np.vstack((spread, np.zeros((missing,) + spread.shape[1:])))
+    return spread
 
 
 def get_waliji_feature_map_from_edges(E2, log_part_blocks, log_invpart_blocks):
@@ -324,18 +371,52 @@ def get_classify_scores_E(utterances, flts_list, linear_filters_cs, bgd=None, is
 
 
 # ---- edge front-end (:2489-2557) ----------------------------------------------------------------
+def _edge_parameters(parameters, use_abst=True):
+    kw = dict(block_length=parameters.block_length, spread_length=parameters.spread_length, threshold=parameters.threshold)
+    if use_abst and getattr(parameters, "abst_threshold", None) is not None:
+        kw["abst_threshold"] = parameters.abst_threshold
+    return kw
+
+
 def get_edge_features(S, parameters, verbose=False):
-    """Spectrogram S [H, T] (features x time, as the reference passes `S.T`) -> thresholded, spread edge
-    map [T, H, 8] (float64 zeros and ones like the reference's; callers cast to uint8).  Only the
-    default branch of the reference (`_edge_map_no_threshold` + `_edge_map_threshold_segments` +
-    `reorg_part_for_fast_filtering`, :2547-2557) -- the magnitude / auxiliary-data variants are not
-    covered.  `parameters` is duck-typed like get_train_data.EdgemapParameters (block_length,
-    spread_length, threshold, optionally abst_threshold)."""
-    for flag in ("auxiliary_data", "magnitude_features", "magnitude_and_edge_features", "magnitude_thresholded_edges"):
-        if getattr(parameters, flag, False):
-            raise NotImplementedError("get_edge_features: only the plain edge-map branch runs on the GPU (%s set)" % flag)
-    return get_edge_corpus([np.asarray(S, np.float64).T], parameters).download_feats().reshape(
-        S.shape[1], S.shape[0], 8).astype(np.float64)
+    """Spectrogram S [H, T] (features x time, as the reference passes `S.T`) -> edge features, with the
+    reference's branches (get_train_data.py:2489-2557); `parameters` is duck-typed like EdgemapParameters.
+      default                      thresholded, spread edge map [T, H, 8] (float64 zeros and ones)
+      magnitude_and_edge_features  [T, 8 H + H'] = the edge map in the reference's orientation-major column
+                                   order beside the whole-block magnitude map (+ 3 auxiliary columns)
+      magnitude_thresholded_edges  the edge strengths masked by the (time-reversed, as in the reference)
+                                   magnitude map before the thresholding, [T, H, 8]
+      magnitude_features           a TypeError, as in the reference (its call lacks an argument, :2494-2498)"""
+    S = np.asarray(S, np.float64)
+    aux = bool(getattr(parameters, "auxiliary_data", False))
+    if aux:
+        A, S = S[-3:], S[:-3]
+    H, T = S.shape
+    if getattr(parameters, "magnitude_features", False):
+        raise TypeError("magnitude_features() takes at least 6 arguments (5 given)")
+    if getattr(parameters, "magnitude_and_edge_features", False):
+        E2 = esp.magnitude_features_whole_block(S, parameters.magnitude_block_length, parameters.magnitude_spread,
+                                                parameters.magnitude_threshold, parameters.mag_smooth_freq,
+                                                parameters.mag_downsample_freq)
+        corpus = api.Corpus.from_spectrograms(np.ascontiguousarray(S.T), [0, T], **_edge_parameters(parameters, use_abst=False))
+        # [T, H, 8] -> the reference's E.T: column e * H + h
+        ET = corpus.download_feats().reshape(T, H, 8).transpose(0, 2, 1).reshape(T, 8 * H).astype(np.float64)
+        if not aux:
+            return np.hstack((ET, E2))
+        AB = esp.magnitude_features(A, parameters.magnitude_block_length, 0, parameters.auxiliary_threshold, 0, 0,
+                                    mag_spread_length=1)
+        return np.hstack((ET, E2, AB))
+    if getattr(parameters, "magnitude_thresholded_edges", False):
+        E2 = esp.magnitude_features_whole_block(S, parameters.magnitude_block_length, parameters.magnitude_spread,
+                                                parameters.magnitude_threshold, parameters.mag_smooth_freq,
+                                                parameters.mag_downsample_freq)
+        if E2.shape[1] != H:
+            raise ValueError("operands could not be broadcast together: the magnitude map has %d bins, the edge map %d"
+                             % (E2.shape[1], H))
+        mask = np.ascontiguousarray(E2[::-1])        # `E2[::-1].T`: the reference flips the time axis here (:2537)
+        corpus = api.Corpus.from_spectrograms(np.ascontiguousarray(S.T), [0, T], mask=mask, **_edge_parameters(parameters))
+        return corpus.download_feats().reshape(T, H, 8).astype(np.float64)
+    return get_edge_corpus([S.T], parameters).download_feats().reshape(T, H, 8).astype(np.float64)
 
 
 def get_edge_corpus(spectrograms, parameters, ctx=None):

@@ -53,6 +53,10 @@ SIGNATURES = {
     "tsr_cluster_times_variable_length": [_p, _p, _p, _i64, _p],
     "tsr_window_peak_max": [_p, _p, _p, _p, _i64, _p, _p, _p, _i64, _p],
     "tsr_edge_corpus_create": [_p, _p, _p, _i64, _i64, _int, _int, C.c_double, _p, _pp],
+    "tsr_edge_corpus_create_masked": [_p, _p, _p, _p, _i64, _i64, _int, _int, C.c_double, _p, _pp],
+    "tsr_threshold_edgemap": [_p, _p, _p, _i32, _i64, C.c_double, _p, _i32, _p],
+    "tsr_spread_edgemap": [_p, _p, _p, _i32, _i64, _p, _i32],
+    "tsr_magnitude_features": [_p, _p, _i64, _i64, _i32, _i32, C.c_double, _i32, _i32, _i32, _i32, _p],
     "tsr_corpus_weighted_sums": [_p, _p, _p, _i64, _p],
     "tsr_mixture_e_step": [_p, _p, _p, _p, _i32, C.POINTER(C.c_double), _p],
     "tsr_mixture_m_step": [_p, _p, _p, _p],

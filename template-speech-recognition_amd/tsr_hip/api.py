@@ -205,7 +205,7 @@ class Corpus:
 
     @classmethod
     def from_spectrograms(cls, S_cat, frame_offsets, block_length=40, spread_length=1, threshold=.7,
-                          abst_threshold=(0.025, 0.025, 0.015, 0.015, 0.02, 0.02, 0.02, 0.02), ctx=None):
+                          abst_threshold=(0.025, 0.025, 0.015, 0.015, 0.02, 0.02, 0.02, 0.02), ctx=None, mask=None):
         """Edge front-end on the device (get_edge_features, get_train_data.py:2547-2557): spectrogram
         stream f64 [sum T, H] (time-major) -> resident binary edge corpus with D = 8 H."""
         ctx = ctx or default_ctx()
@@ -217,6 +217,14 @@ class Corpus:
         if ab.shape != (8,):
             raise ValueError("abst_threshold needs 8 values")
         h = C.c_void_p()
+        if mask is not None:   # u8 [sum T, H]: edge strengths are zeroed where it is 0 (magnitude_thresholded_edges)
+            mk = np.ascontiguousarray(mask, dtype=np.uint8)
+            if mk.shape != S.shape:
+                raise ValueError("mask must have the spectrogram stream's shape %r" % (S.shape,))
+            check(lib().tsr_edge_corpus_create_masked(ctx._h, ptr(S), ptr(mk), ptr(offs), len(offs) - 1, S.shape[1],
+                                                      int(block_length), int(spread_length), float(threshold), ptr(ab),
+                                                      C.byref(h)))
+            return cls._adopt(h, ctx)
         check(lib().tsr_edge_corpus_create(ctx._h, ptr(S), ptr(offs), len(offs) - 1, S.shape[1], int(block_length),
                                            int(spread_length), float(threshold), ptr(ab), C.byref(h)))
         return cls._adopt(h, ctx)

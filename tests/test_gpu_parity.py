@@ -1093,3 +1093,106 @@ def test_g15_code_parts_mag_aux(mods, oracle):
         assert np.array_equal(cp.code_parts_mag_aux(*args), oracle.code_parts_mag_aux(*args))
     with pytest.raises(ValueError):
         cp.code_parts_mag_aux(Xe, Xm, Xa, lp.astype(np.float32), lip, lmp, lmip, lap, laip, mask)
+
+
+# ---- the rest of the edge front-end: thresholding / spreading / magnitude maps ------------------
+def _edges2_cases():
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_edges2 as mg
+    return mg
+
+
+def test_g23_edges2_from_the_references_own_code(mods, oracle):
+    """g23 on the device: threshold_edgemap, spread_edgemap, magnitude_features, magnitude_features_whole_block and
+    the magnitude / auxiliary branches of get_edge_features / get_part_features, against the outputs of the
+    reference's own Python code -- identical."""
+    from template_speech_rec import edge_signal_proc as esp
+    from template_speech_rec import get_train_data as gtrd
+    mg = _edges2_cases()
+    g = golden("g23_edges2_reftext")
+    for i in range(int(g["te_n"])):
+        H, q, binary, sl = g["te%d_p" % i]
+        E = g["te%d_E" % i].astype(np.float64)
+        breaks = np.arange(9) * int(H)
+        assert esp.threshold_edgemap(E, float(q), breaks, abst_threshold=oracle.ABST_THRESHOLD, convert_to_binary=bool(binary)) is None
+        assert np.array_equal(E, g["te%d_thr" % i].astype(np.float64)), i
+        esp.spread_edgemap(E, breaks, oracle.EDGE_ORIENTATIONS, spread_length=int(sl))
+        assert np.array_equal(E, g["te%d_spread" % i].astype(np.float64)), i
+    for i in range(int(g["mg_n"])):
+        bl, sr, q, sm, dn, msl = g["mg%d_p" % i]
+        S = g["mg%d_S" % i].astype(np.float64)
+        a = esp.magnitude_features(S, int(bl), int(sr), float(q), int(sm), int(dn), mag_spread_length=int(msl))
+        assert a.dtype == np.uint8 and np.array_equal(a, g["mg%d_bin" % i]), i
+        assert np.array_equal(esp.magnitude_features_whole_block(S, int(bl), int(sr), float(q), int(sm), int(dn)), g["mg%d_whole" % i]), i
+    S = g["ef_S"].astype(np.float64)
+    H = S.shape[0] - 3
+    for name, p in mg.EDGE_CASES:
+        Sin = S if p.auxiliary_data else S[:H]
+        got = gtrd.get_edge_features(Sin.copy(), p)
+        assert got.shape == g["ef_" + name].shape and np.array_equal(got, g["ef_" + name]), name
+    with pytest.raises(TypeError):          # the reference's magnitude_features branch calls with an argument missing
+        gtrd.get_edge_features(S[:H], mg.edge_params(magnitude_features=True))
+    for i in range(int(g["pf_n"])):
+        nm, na, K = (int(x) for x in g["pf%d_p" % i])
+        p = mg.PartP(True, True, nm, na, *[g["pf%d_%s" % (i, f)] for f in mg.PART_TABLES], 2, 1, K, None, 12)
+        got = gtrd.get_part_features(g["pf%d_E" % i], p)
+        assert got.shape == g["pf%d_out" % i].shape and np.array_equal(got, g["pf%d_out" % i]), i
+
+
+def test_edges2_random_vs_oracle(mods, oracle):
+    from template_speech_rec import edge_signal_proc as esp
+    rng = np.random.default_rng(2301)
+    for trial in range(30):
+        H, T = int(rng.integers(1, 40)), int(rng.integers(1, 300))
+        nb = int(rng.integers(1, 9))
+        E = rng.standard_normal((nb * H + 2, T)) * rng.choice([0.02, 1.0])
+        if trial % 3 == 0:
+            E = np.round(E * 4) / 4              # ties at the quantile
+        if trial % 5 == 0:
+            E[:H] = -np.abs(E[:H])               # a block without positive values
+        breaks = np.arange(nb + 1) * H + (1 if trial % 4 == 0 else 0)     # rows outside the breaks stay untouched
+        q, binary = float(rng.choice([0.0, .3, .7, .999])), bool(trial % 2)
+        abst = rng.uniform(0, 0.05, size=nb)
+        want = E.copy()
+        taus = oracle.threshold_edgemap(want, q, breaks, abst, binary)
+        if trial % 6 == 1:                       # a non-contiguous caller array is updated in place as well
+            big = np.zeros((E.shape[0], 2 * T))
+            view = big[:, ::2]
+            view[...] = E
+            esp.threshold_edgemap(view, q, breaks, abst_threshold=abst, convert_to_binary=binary)
+            got = view.copy()
+        else:
+            got = E.copy()
+            r = esp.threshold_edgemap(got, q, breaks, report_level=True, abst_threshold=abst, convert_to_binary=binary)
+            assert np.array_equal(r[1], taus, equal_nan=True) and np.array_equal(r[0], got)
+        assert np.array_equal(got, want), trial
+        orient = rng.integers(-1, 2, size=(nb, 2))       # (steps beyond +-1 overrun the reference's zero padding)
+        sl = int(rng.integers(1, 5))
+        oracle.spread_edgemap(want, breaks, orient, sl)
+        esp.spread_edgemap(got, breaks, orient, spread_length=sl)
+        assert np.array_equal(got, want), trial
+    with pytest.raises(ValueError):
+        esp.spread_edgemap(np.zeros((8, 5)), np.arange(9), oracle.EDGE_ORIENTATIONS, spread_length=0)
+    with pytest.raises(ValueError):
+        esp.threshold_edgemap(np.zeros((8, 5)), 1.0, np.arange(9))
+    done = 0
+    for trial in range(60):
+        F, T = int(rng.integers(1, 70)), int(rng.integers(8, 500))
+        S = rng.standard_normal((F, T))
+        if trial % 4 == 0:
+            S = np.round(S * 3) / 3
+        bl, q = int(rng.choice([4, 8, 20, 40, 41, 64])), float(rng.choice([0.0, .5, .7, .9]))
+        sm, dn, msl, sr = int(rng.integers(0, 6)), int(rng.integers(0, 4)), int(rng.integers(0, 3)), int(rng.integers(0, 8))
+        try:
+            want = oracle.magnitude_features(S, bl, sr, q, sm, dn, msl)
+            want2 = oracle.magnitude_features_whole_block(S, bl, sr, q, sm, dn)
+        except IndexError:                       # a rank past a short window: ValueError in the drop-in
+            with pytest.raises(ValueError):
+                esp.magnitude_features(S, bl, sr, q, sm, dn, mag_spread_length=msl)
+                esp.magnitude_features_whole_block(S, bl, sr, q, sm, dn)
+            continue
+        done += 1
+        assert np.array_equal(esp.magnitude_features(S, bl, sr, q, sm, dn, mag_spread_length=msl), want), trial
+        assert np.array_equal(esp.magnitude_features_whole_block(S, bl, sr, q, sm, dn), want2), trial
+    assert done > 30

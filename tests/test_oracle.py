@@ -274,3 +274,34 @@ def test_g15_code_parts_mag_aux(oracle):
     for i in range(int(g["n"])):
         args, want = _g15_case(g, i)
         assert np.array_equal(oracle.code_parts_mag_aux(*args), want), i
+
+
+def test_g23_edge_threshold_spread_magnitude_from_the_references_own_code(oracle):
+    """g23: the reference's threshold_edgemap / spread_edgemap / magnitude_features(_whole_block) and the
+    magnitude / auxiliary branches of get_edge_features / get_part_features (run through oracle/py2ref.py)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_edges2 as mg
+    g = golden("g23_edges2_reftext")
+    for i in range(int(g["te_n"])):
+        H, q, binary, sl = g["te%d_p" % i]
+        E = g["te%d_E" % i].astype(np.float64)
+        breaks = np.arange(9) * int(H)
+        oracle.threshold_edgemap(E, float(q), breaks, oracle.ABST_THRESHOLD, bool(binary))
+        assert np.array_equal(E, g["te%d_thr" % i].astype(np.float64))
+        oracle.spread_edgemap(E, breaks, oracle.EDGE_ORIENTATIONS, int(sl))
+        assert np.array_equal(E, g["te%d_spread" % i].astype(np.float64))
+    for i in range(int(g["mg_n"])):
+        bl, sr, q, sm, dn, msl = g["mg%d_p" % i]
+        S = g["mg%d_S" % i].astype(np.float64)
+        assert np.array_equal(oracle.magnitude_features(S, int(bl), int(sr), float(q), int(sm), int(dn), int(msl)), g["mg%d_bin" % i])
+        assert np.array_equal(oracle.magnitude_features_whole_block(S, int(bl), int(sr), float(q), int(sm), int(dn)), g["mg%d_whole" % i])
+    S = g["ef_S"].astype(np.float64)
+    H = S.shape[0] - 3
+    for name, p in mg.EDGE_CASES:
+        Sin = S if p.auxiliary_data else S[:H]
+        assert np.array_equal(oracle.get_edge_features_with_parameters(Sin.copy(), p), g["ef_" + name]), name
+    for i in range(int(g["pf_n"])):
+        nm, na, K = (int(x) for x in g["pf%d_p" % i])
+        p = mg.PartP(True, True, nm, na, *[g["pf%d_%s" % (i, f)] for f in mg.PART_TABLES], 2, 1, K, None, 12)
+        assert np.array_equal(oracle.get_part_features_mag_aux(g["pf%d_E" % i], p), g["pf%d_out" % i])

@@ -298,3 +298,68 @@ def test_dropin_example_bookkeeping_is_the_references_code():
         got = gtd.get_examples_from_phns_ftls(syl, phns, flts, lpb, int(flts[-1]) // 2)
         for a, b in zip(want, got):
             assert (a is None and b is None) or np.array_equal(a, b), case
+
+
+def test_edge_threshold_spread_and_magnitude_restatements_are_the_references_code(oracle):
+    """threshold_edgemap / spread_edgemap / magnitude_features / magnitude_features_whole_block and the branches
+    of get_edge_features / get_part_features (mag + aux): oracle/oracle.py against the reference's own code
+    (SciPy supplying maximum_filter / correlate / convolve as in the reference's imports)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_edges2 as mg
+    esp, gtd = mg.reference_functions()
+    rng = np.random.default_rng(77)
+    for trial in range(40):
+        H, T = int(rng.integers(3, 24)), int(rng.integers(5, 100))
+        E = rng.standard_normal((8 * H, T)) * rng.choice([0.02, 1.0])
+        if trial % 3 == 0:
+            E = np.round(E * 4) / 4
+        if trial % 7 == 0:
+            E[2 * H:3 * H] = -np.abs(E[2 * H:3 * H])
+        q, binary, breaks = float(rng.choice([0.0, .3, .7, .95])), bool(trial % 2), np.arange(9) * H
+        A, B = E.copy(), E.copy()
+        allpos = (A > 0).reshape(8, -1).any(1).all()
+        r = esp["threshold_edgemap"](A, q, breaks, report_level=bool(allpos), abst_threshold=oracle.ABST_THRESHOLD,
+                                     convert_to_binary=binary)
+        taus = oracle.threshold_edgemap(B, q, breaks, oracle.ABST_THRESHOLD, binary)
+        assert np.array_equal(A, B) and (r is None or np.array_equal(r[1], taus))
+        sl = int(rng.integers(1, 4))
+        esp["spread_edgemap"](A, breaks, oracle.EDGE_ORIENTATIONS, spread_length=sl)
+        oracle.spread_edgemap(B, breaks, oracle.EDGE_ORIENTATIONS, sl)
+        assert np.array_equal(A, B)
+    done = 0
+    for trial in range(80):
+        F, T = int(rng.integers(3, 40)), int(rng.integers(30, 200))
+        S = rng.standard_normal((F, T))
+        if trial % 4 == 0:
+            S = np.round(S * 3) / 3
+        bl, q = int(rng.choice([8, 20, 40, 41])), float(rng.choice([.5, .7, .9]))
+        sm, dn, msl, sr = int(rng.integers(0, 5)), int(rng.integers(0, 3)), int(rng.integers(0, 3)), int(rng.integers(0, 8))
+        try:
+            a = esp["magnitude_features"](S.copy(), bl, sr, q, sm, dn, mag_spread_length=msl)
+            a2 = esp["magnitude_features_whole_block"](S.copy(), bl, sr, q, sm, dn)
+        except IndexError:           # a rank past a short window: the reference fails there
+            continue
+        done += 1
+        assert np.array_equal(a, oracle.magnitude_features(S.copy(), bl, sr, q, sm, dn, msl))
+        assert np.array_equal(a2, oracle.magnitude_features_whole_block(S.copy(), bl, sr, q, sm, dn))
+    assert done > 40
+    for trial in range(6):
+        H, T = int(rng.integers(6, 24)), int(rng.integers(50, 130))
+        S = rng.standard_normal((H + 3, T))
+        for kw in (dict(magnitude_and_edge_features=True, magnitude_spread=int(rng.integers(0, 3))),
+                   dict(magnitude_and_edge_features=True, auxiliary_data=True, magnitude_block_length=20),
+                   dict(magnitude_thresholded_edges=True, magnitude_threshold=.4),
+                   dict(magnitude_thresholded_edges=True, auxiliary_data=True, spread_length=2, block_length=25), dict()):
+            p = mg.edge_params(**kw)
+            Sin = S if p.auxiliary_data else S[:H]
+            assert np.array_equal(np.asarray(gtd["get_edge_features"](Sin.copy(), p)),
+                                  oracle.get_edge_features_with_parameters(Sin.copy(), p)), kw
+    flips = 0
+    for trial in range(5):
+        T, F, K = int(rng.integers(12, 50)), int(rng.integers(6, 16)), int(rng.integers(2, 7))
+        E, p = mg.mag_aux_case(rng, T, F, K, int(rng.integers(1, 5)), int(rng.integers(1, 4)))
+        want = np.asarray(gtd["get_part_features"](E.copy(), p))
+        got = oracle.get_part_features_mag_aux(E.copy(), p)
+        assert got.shape == want.shape
+        flips += int((got != want).sum())       # (only a Gaussian count within float32 rounding of 12 could differ)
+    assert flips == 0
