@@ -68,7 +68,11 @@ enum {
  *              than 16 bits.
  *   TSR_FAST | TSR_W24: three limbs (23-bit weights, power-of-two scale),
  *              <= 2^-22 * max|W_m| per set tap, at 1.5x the matrix-core work. */
-enum { TSR_EXACT = 0, TSR_FAST = 1, TSR_W24 = 2 };
+enum { TSR_EXACT = 0, TSR_FAST = 1, TSR_W24 = 2, TSR_BF16 = 4 };
+/*   TSR_FAST | TSR_BF16 [| TSR_W24]: the bank as a bf16 MFMA GEMM (BASELINE configs[4]): weights rounded to bf16
+ *              (relative error up to 2^-9 per weight: NOT within the 1e-4 bar) or, with TSR_W24, split into
+ *              bf16 hi + lo (2^-17 per weight), f32 accumulation and f32 LDS atomics -- neither exact nor
+ *              bit-reproducible.  Comparison variants only; D <= 384, otherwise the exact kernel serves the call. */
 
 typedef struct tsr_ctx tsr_ctx;       /* device + stream + scratch                 */
 typedef struct tsr_bank tsr_bank;     /* device-resident template bank             */

@@ -83,22 +83,43 @@ static void fast_bank_free_one(tsr_bank *bank, int which)
 
 void tsr_fast_bank_free(tsr_bank *bank)
 {
-    fast_bank_free_one(bank, 0);
-    fast_bank_free_one(bank, 1);
+    for (int k = 0; k < 4; ++k) fast_bank_free_one(bank, k);
 }
 
-// NL = 2: 16-bit fixed point (two int8 limbs, int32 ring); NL = 3: 23-bit (three limbs,
-// int64 ring).  Built lazily, cached in bank->fast[NL - 2].
-int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int NL)
+static uint16_t bf16_rn(float x)  // round to nearest even (finite inputs)
 {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float bf16_value(uint16_t h)
+{
+    const uint32_t u = (uint32_t)h << 16;
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
+
+// kind 0: 16-bit fixed point (two int8 limbs, int32 ring); 1: 23-bit (three limbs, int64 ring); 2: bf16
+// weights; 3: bf16 hi + lo.  Built lazily, cached in bank->fast[kind].
+int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int kind)
+{
+    const bool bf = kind >= 2;
+    const int NL = bf ? kind - 1 : kind + 2;
     const int M = bank->M;
     const int64_t D = bank->D;
-    const int nkb_total = (int)((D + 31) / 32);
+    if (bf && D > 16 * kBfSteps) {
+        tsr_set_error("TSR_BF16: D=%lld exceeds the %d features of the bf16 variant", (long long)D, 16 * kBfSteps);
+        return TSR_ERR_UNSUPPORTED;
+    }
+    const int nkb_total = bf ? kBfSteps : (int)((D + 31) / 32);
     // Feature rows wider than one wave's register budget (kMaxNKB K-blocks) are split into
     // K-phases: each phase is a complete kernel pass over its own feature range with its own
     // register-stationary limbs; the phases' partial raw scores are summed by the epilogue.
-    const int n_phase = (nkb_total + kMaxNKB - 1) / kMaxNKB;
-    const int NKB = (nkb_total + n_phase - 1) / n_phase;
+    // (bf16: one pass of kBfSteps 16-feature steps, the kernel is instantiated for exactly that)
+    const int n_phase = bf ? 1 : (nkb_total + kMaxNKB - 1) / kMaxNKB;
+    const int NKB = bf ? kBfSteps : (nkb_total + n_phase - 1) / n_phase;
     const int KS = 1;
     const int CT = kWaves / KS;
     const int64_t C = bank->sumL;
@@ -110,7 +131,8 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int NL)
     // NL = 2: q = rint(W * qmax / max|W|), qmax = min(127*256, (2^31-1) / (L_m * D)) so that the
     //         int32 ring cannot overflow even if every feature of every tap is set.
     std::vector<double> inv_scale(M);
-    std::vector<int8_t> limbs((size_t)NL * C * D);  // [limb][column][d]
+    std::vector<int8_t> limbs(bf ? 0 : (size_t)NL * C * D);      // [limb][column][d]
+    std::vector<uint16_t> blimbs(bf ? (size_t)NL * C * D : 0);   // bf16: hi (and lo = rn(W - hi))
     std::vector<int32_t> col_tmpl((size_t)C), col_tau_v((size_t)C);
     {
         int64_t woff = 0, c0 = 0;
@@ -120,7 +142,7 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int NL)
             float mx = 0.0f;
             for (int64_t i = 0; i < n; ++i) mx = std::max(mx, fabsf(w[i]));
             double sc = 1.0;
-            if (mx > 0.0f) {
+            if (mx > 0.0f && !bf) {
                 if (NL == 3) {
                     int ex;
                     frexpf(mx, &ex);  // mx = f * 2^ex, f in [0.5, 1)  =>  mx * 2^(22-ex) in [2^21, 2^22)
@@ -134,12 +156,22 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int NL)
                     sc = qmax / (double)mx;
                 }
             }
+            if (mx > 0.0f && bf) {  // fixed point of the tile sums in the int32 ring: 2^e * (all taps set) < 2^30
+                const int e = (int)floor(log2(1073741824.0 / ((double)n * (double)mx)));
+                sc = ldexp(1.0, std::max(-60, std::min(e, 60)));
+            }
             inv_scale[m] = 1.0 / sc;
             for (int tau = 0; tau < bank->L[m]; ++tau) {
                 const int64_t c = c0 + tau;
                 col_tmpl[(size_t)c] = m;
                 col_tau_v[(size_t)c] = tau;
-                for (int64_t d = 0; d < D; ++d) {
+                for (int64_t d = 0; bf && d < D; ++d) {
+                    const float x = w[tau * D + d];
+                    const uint16_t hi = bf16_rn(x);
+                    blimbs[((size_t)0 * C + c) * D + d] = hi;
+                    if (NL == 2) blimbs[((size_t)1 * C + c) * D + d] = bf16_rn(x - bf16_value(hi));
+                }
+                for (int64_t d = 0; !bf && d < D; ++d) {
                     int q = (int)llrint((double)w[tau * D + d] * sc);
                     for (int l = 0; l < NL; ++l) {  // balanced base-256 digits, last one keeps the rest
                         int digit = (l == NL - 1) ? q : ((q + 128) & 255) - 128;
@@ -217,6 +249,13 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int NL)
                         if (c >= C) continue;
                         int8_t *dst = reinterpret_cast<int8_t *>(
                             &Wl[ph * wl_phase + (((size_t)tile * NKB + kb) * NL + l) * 64 + lane]);
+                        if (bf) {  // v_mfma_f32_32x32x16_bf16 B operand: lane (col, h) holds k = 16 kb + 8 h + 0..7
+                            uint16_t *d16 = reinterpret_cast<uint16_t *>(dst);
+                            const int64_t k0 = (int64_t)kb * 16 + 8 * (lane >> 5);
+                            for (int e = 0; e < 8; ++e)
+                                if (k0 + e < D) d16[e] = blimbs[((size_t)l * C + c) * D + k0 + e];
+                            continue;
+                        }
                         const int64_t k0 = ((int64_t)ph * NKB + kb) * 32 + 16 * (lane >> 5);
                         for (int e = 0; e < 16; ++e)
                             if (k0 + e < D) dst[e] = limbs[((size_t)l * C + c) * D + k0 + e];
@@ -233,7 +272,7 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int NL)
     fb->max_slots = max_slots;
     fb->n_phase = n_phase;
     fb->wl_phase = wl_phase;
-    bank->fast[NL - 2] = fb;
+    bank->fast[kind] = fb;
     int s = upload(ctx, &fb->d_Wl, Wl);
     if (s == TSR_OK) s = upload(ctx, &fb->d_col_slot, col_slot);
     if (s == TSR_OK) s = upload(ctx, &fb->d_col_tau, col_tau);
@@ -242,7 +281,7 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int NL)
     if (s == TSR_OK) s = upload(ctx, &fb->d_frag_idx, frag_idx);
     if (s == TSR_OK) s = upload(ctx, &fb->d_slots, slots);
     if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
-    if (s != TSR_OK) fast_bank_free_one(bank, NL - 2);
+    if (s != TSR_OK) fast_bank_free_one(bank, kind);
     return s;
 }
 
@@ -308,15 +347,19 @@ static int build_plan(tsr_ctx *ctx, tsr_corpus *cp, int nseg, int Lmax)
 int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int flags,
                          float *d_scores, int32_t *d_ids, float *d_all)
 {
-    const int NL = (flags & TSR_W24) ? 3 : 2;
-    const FastBank *fb = static_cast<const FastBank *>(bank->fast[NL - 2]);
+    const bool bf = (flags & TSR_BF16) != 0;
+    const int kind = (bf ? 2 : 0) + ((flags & TSR_W24) ? 1 : 0);
+    const int NL = bf ? kind - 1 : kind + 2;
+    const FastBank *fb = static_cast<const FastBank *>(bank->fast[kind]);
     if (!fb) return TSR_ERR_UNSUPPORTED;
     const int64_t P = cp->P;
     if (P == 0) return TSR_OK;
-    const int Dp = cp->Dp;
+    if (bf) TSR_TRY(tsr_corpus_bf16_copy(ctx, cp));
+    // (bf16: the "row" is the bf16 copy's, its stride already an odd number of 16-byte slots)
+    const int Dp = bf ? cp->bf16_stride : cp->Dp;
     // LDS row: the bytes one pass needs of a frame (the whole resident row, or one K-phase of
     // it), as an odd number of 16-byte slots so that b128 fragment reads are conflict-free
-    const int k_span = fb->KS * fb->NKB * 32;
+    const int k_span = fb->KS * fb->NKB * 32;  // bytes of a row one pass reads (int8: 32 features per K-block; bf16: 16)
     int row_bytes = fb->n_phase == 1 ? Dp : k_span;  // source bytes copied per frame and pass
     int SB = row_bytes;
     if (((SB >> 4) & 1) == 0) SB += 16;
@@ -333,7 +376,7 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
     while (ring < 32 * (lag + 8)) ring *= 2;
     const size_t lds = (size_t)5 * tile_bytes + (size_t)kMaxSlots * sizeof(SlotMeta) +
                        (size_t)(ring + 64) * 4 + (size_t)ring * 8 +
-                       (size_t)(fb->max_slots + 1) * (ring + 33) * (NL == 2 ? 4 : 8) + 16;
+                       (size_t)(fb->max_slots + 1) * (ring + 33) * ((bf || NL == 2) ? 4 : 8) + 64;
     if (lds > 160 * 1024) {
         tsr_set_error("TSR_FAST: D=%lld, Lmax=%d need %zu bytes of LDS", (long long)bank->D, bank->Lmax, lds);
         return TSR_ERR_UNSUPPORTED;
@@ -342,6 +385,18 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
     int nseg = std::max(1, ctx->cus / fb->G);
     const int64_t min_rows = 64;  // do not cut the stream finer than two tiles per segment
     nseg = (int)std::max<int64_t>(1, std::min<int64_t>(nseg, (P + min_rows - 1) / min_rows));
+    // Several column groups: the G workgroups of a segment go to one XCD (so that its L2 serves the
+    // re-reads), in two rounds of workgroups per CU slot: spx = floor(2 * CUs-per-XCD / G) segments per XCD
+    // keep >= 98 % of the slots busy for G <= 9 where one round would leave up to G - 1 of 32 idle.
+    int spx = 0;
+    if (fb->G > 1 && fb->G <= 2 * (ctx->cus / 8)) {
+        const char *e = getenv("TSR_XCD_MAP");
+        const int want = (2 * (ctx->cus / 8)) / fb->G;
+        if (!(e && e[0] == '0') && want >= 1 && (int64_t)8 * want * min_rows * 4 <= P) {
+            spx = want;
+            nseg = 8 * spx;
+        }
+    }
     TSR_TRY(build_plan(ctx, cp, nseg, bank->Lmax));
 
     const bool fragments = fb->n_phase > 1 || fb->G > 1;
@@ -357,7 +412,7 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
     for (int ph = 0; ph < fb->n_phase; ++ph) {
         FastArgs a;
         memset(&a, 0, sizeof a);
-        a.X = cp->d_feats + (size_t)ph * k_span;  // this phase's feature range of every row
+        a.X = bf ? reinterpret_cast<const uint8_t *>(cp->d_feats_bf16) : cp->d_feats + (size_t)ph * k_span;  // this phase's feature range of every row
         a.Dp = Dp;
         a.SB = SB;
         a.src_slots = row_bytes >> 4;
@@ -366,6 +421,7 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
         a.CT = fb->CT;
         a.KS = fb->KS;
         a.nseg = nseg;
+        a.spx = spx;
         a.seg = cp->d_plan;
         a.Wl = fb->d_Wl + (size_t)ph * fb->wl_phase;
         a.col_slot = fb->d_col_slot;
@@ -386,6 +442,15 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
             a.all = d_all;
         }
         int s;
+        if (bf) {
+            // the kernel is instantiated for exactly this geometry: refuse anything else rather than launch
+            if (fb->NKB != kBfSteps || fb->n_phase != 1 || !flat || a.Dp != cp->bf16_stride || tile_bytes < 32 * SB + 32) {
+                tsr_set_error("TSR_BF16: internal geometry mismatch (NKB=%d, phases=%d, flat=%d)", fb->NKB, fb->n_phase, (int)flat);
+                return TSR_ERR_UNSUPPORTED;
+            }
+            TSR_TRY(launch_bf16(ctx, a, grid, lds, NL));
+            continue;
+        }
         switch (fb->NKB) {
         case 1: s = launch<1>(ctx, a, grid, lds, NL, flat); break;
         case 2: s = launch<2>(ctx, a, grid, lds, NL, flat); break;

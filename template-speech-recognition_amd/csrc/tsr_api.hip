@@ -441,6 +441,7 @@ TSR_API int tsr_corpus_destroy(tsr_corpus *cp)
     dev_free(cp->d_ids);
     dev_free(cp->d_plan);
     dev_free(cp->d_aff);
+    dev_free(cp->d_feats_bf16);
     delete cp;
     return TSR_OK;
 }
@@ -457,14 +458,14 @@ static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp,
 {
     TSR_REQUIRE(ctx && bank && cp, "tsr_corpus_score: null pointer");
     TSR_REQUIRE(bank->D == cp->D, "tsr_corpus_score: bank D=%lld but corpus D=%lld", (long long)bank->D, (long long)cp->D);
-    TSR_REQUIRE((flags & ~(TSR_FAST | TSR_W24)) == 0, "tsr_corpus_score: unknown flags 0x%x", flags);
-    TSR_REQUIRE(!(flags & TSR_W24) || (flags & TSR_FAST), "tsr_corpus_score: TSR_W24 modifies TSR_FAST");
+    TSR_REQUIRE((flags & ~(TSR_FAST | TSR_W24 | TSR_BF16)) == 0, "tsr_corpus_score: unknown flags 0x%x", flags);
+    TSR_REQUIRE(!(flags & (TSR_W24 | TSR_BF16)) || (flags & TSR_FAST), "tsr_corpus_score: TSR_W24 / TSR_BF16 modify TSR_FAST");
     if (cp->P == 0) return TSR_OK;
     TSR_HIP(hipSetDevice(ctx->device));
     // Short filters (few thousand taps) produce scores of order one, against which the 16-bit
     // quantisation noise is no longer small; their launch is latency-bound anyway, so TSR_FAST
     // takes the third limb there at no measurable cost (include/tsr.h, "at least 16-bit weights").
-    if (flags & TSR_FAST) {
+    if ((flags & TSR_FAST) && !(flags & TSR_BF16)) {
         int32_t Lmin = bank->Lmax;
         for (int32_t l : bank->L) Lmin = std::min(Lmin, l);
         if ((int64_t)Lmin * bank->D <= TSR_FAST_W24_BELOW_TAPS) flags |= TSR_W24;  // (the shortest filter decides)
@@ -474,9 +475,9 @@ static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp,
         if ((int64_t)bank->Lmax * bank->D > TSR_FAST_W24_ABOVE_TAPS) flags |= TSR_W24;
     }
     if (flags & TSR_FAST) {
-        const int NL = (flags & TSR_W24) ? 3 : 2;
-        if (!bank->fast[NL - 2]) {
-            int sb = tsr_fast_bank_build(ctx, const_cast<tsr_bank *>(bank), NL);
+        const int kind = ((flags & TSR_BF16) ? 2 : 0) + ((flags & TSR_W24) ? 1 : 0);
+        if (!bank->fast[kind]) {
+            int sb = tsr_fast_bank_build(ctx, const_cast<tsr_bank *>(bank), kind);
             if (sb != TSR_OK && sb != TSR_ERR_UNSUPPORTED) return sb;
         }
         int s = tsr_launch_fast_bank(ctx, bank, cp, flags, d_all ? nullptr : cp->d_scores,

@@ -99,8 +99,8 @@ struct tsr_bank {
     int32_t *d_gx_L = nullptr;
     int32_t *d_L = nullptr;          // [M]
     float *d_cf = nullptr;           // [M]  f32(c_m)
-    // device, fast path (built lazily by detect_mfma.hip): [0] two limbs, [1] three limbs
-    void *fast[2] = {nullptr, nullptr};
+    // device, fast path (built lazily by detect_mfma.hip): [0] two int8 limbs, [1] three, [2] bf16, [3] bf16 hi + lo
+    void *fast[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 struct tsr_corpus {
@@ -119,6 +119,8 @@ struct tsr_corpus {
     int plan_key = 0;                // (segments, Lmax) the plan was built for
     int plan_nseg = 0;
     int32_t *d_plan = nullptr;       // [3][nseg]: first output, end of outputs, end of rows
+    uint16_t *d_feats_bf16 = nullptr; // bf16 copy of the frames (rows of bf16_stride bytes), built on first use by TSR_BF16
+    int bf16_stride = 0;
     // Bernoulli mixture: the posterior component probabilities the latest E-step left on the device
     float *d_aff = nullptr;          // [P][aff_K]
     int64_t aff_K = 0, aff_cap = 0;  // columns in use; capacity in floats
@@ -200,7 +202,8 @@ int tsr_launch_code_parts_mfma(tsr_ctx *ctx, const tsr_parts *p, const uint8_t *
                                int Dp, const int32_t *d_utt_end, int threshold, int fast, int32_t *d_argmax,
                                uint32_t *d_list, int *d_work);
 // detect_mfma.hip
-int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int NL);
+int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int kind);  // kind: index into tsr_bank::fast
+int tsr_corpus_bf16_copy(tsr_ctx *ctx, struct tsr_corpus *cp);
 void tsr_fast_bank_free(tsr_bank *bank);
 int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *corpus, int flags,
                          float *d_scores, int32_t *d_ids, float *d_all);

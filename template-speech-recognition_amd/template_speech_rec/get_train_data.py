@@ -289,6 +289,39 @@ def _isolated_virtual_windows(T, flts, max_filter_length, frame0=0):
     return first, real_lo, real_hi, rows, we - ws, ws, int(f[0]), pad
 
 
+def _isolated_virtual_windows_batch(Ts, flts_list, max_filter_length, frame0s):
+    """_isolated_virtual_windows for a whole corpus in one pass of array operations (the per-utterance Python
+    loop took 17 ms for 1000 utterances -- six times the kernel it feeds).  Returns the concatenated
+    (first, real_lo, real_hi, rows, n_valid, window_starts) and per utterance (phone count, f[0])."""
+    n_ph = np.array([len(f) - 1 for f in flts_list], dtype=np.int64)
+    if (n_ph < 1).any():
+        raise ValueError("every utterance needs at least one phone (two boundaries)")
+    N = len(flts_list)
+    F = np.concatenate([np.asarray(f, dtype=np.int64) for f in flts_list])
+    Ts = np.asarray(Ts, dtype=np.int64)
+    frame0s = np.asarray(frame0s, dtype=np.int64)
+    b0 = np.concatenate(([0], np.cumsum(n_ph + 1)))[:-1]          # index in F of each utterance's first boundary
+    p0 = np.concatenate(([0], np.cumsum(n_ph)))                    # index of each utterance's first phone
+    utt = np.repeat(np.arange(N), n_ph)
+    left = b0[utt] + (np.arange(p0[-1]) - p0[:-1][utt])
+    fl, fr = F[left], F[left + 1]
+    third = np.ceil(np.maximum.reduceat(fr - fl, p0[:-1]) / 3.).astype(np.int64)
+    pad = max_filter_length + third
+    last, second_last = F[b0 + n_ph], F[b0 + n_ph - 1]
+    len_padded = pad + Ts + np.maximum(0, second_last + third + max_filter_length - last)
+    gl, gr = fl + pad[utt], fr + pad[utt]
+
+    def i16(x):                                                    # the reference stores these as int16
+        return x.astype(np.int16).astype(np.int64)
+
+    ws, we, pse = i16(gl + (gl - gr) / 3.), i16(gl + (gr - gl) / 3.), i16(gr + (gr - gl) / 3.)
+    avail_end = np.minimum(pse, len_padded[utt])
+    rows = (avail_end - ws) + np.maximum(0, we + max_filter_length - pse)
+    first = frame0s[utt] + ws - pad[utt]
+    real_hi = frame0s[utt] + np.clip(avail_end - pad[utt], 0, Ts[utt])
+    return first, frame0s[utt].copy(), real_hi, rows, we - ws, ws, n_ph, F[b0] + pad
+
+
 def _compute_isolated_classification_E(E, phns, E_flts, utt_id, classify_array, classify_template_ids,
                                        classify_template_lengths, classify_locs, linear_filters_cs, bgd,
                                        phn_mapping=None, verbose=False, svm_classifiers=None,
@@ -357,16 +390,17 @@ def get_classify_scores_E(utterances, flts_list, linear_filters_cs, bgd=None, is
     offs = np.concatenate(([0], np.cumsum([m.shape[0] for m in maps]))).astype(np.int64)
     corpus = api.Corpus(np.concatenate([m.reshape(m.shape[0], -1) for m in maps]), offs, ctx=bank.ctx)
     Lmax = max(len(lfc[0]) for lfc in linear_filters_cs)
-    per = [_isolated_virtual_windows(m.shape[0], f, Lmax, frame0=int(offs[n]))
-           for n, (m, f) in enumerate(zip(maps, flts_list))]
-    cat = [np.concatenate([p[i] for p in per]) for i in range(5)]
-    score, pos, tid = corpus.classify_isolated(bank, bgd, *cat)
-    k = 0
-    for n, p in enumerate(per):
-        m = len(p[5])
-        _store_classification(n, score[k:k + m], p[5] + pos[k:k + m] - p[6], tid[k:k + m], linear_filters_cs,
-                              classify_array, classify_template_ids, classify_template_lengths, classify_locs)
-        k += m
+    first, lo, hi, rows, n_valid, ws, n_ph, f0 = _isolated_virtual_windows_batch(
+        [m.shape[0] for m in maps], flts_list, Lmax, offs[:-1])
+    score, pos, tid = corpus.classify_isolated(bank, bgd, first, lo, hi, rows, n_valid)
+    # results into the [N, max phones] arrays in one scatter (what _store_classification does per utterance)
+    utt = np.repeat(np.arange(N), n_ph)
+    col = np.arange(len(utt)) - np.repeat(np.cumsum(n_ph) - n_ph, n_ph)
+    lengths = np.array([len(lfc[0]) for lfc in linear_filters_cs])
+    classify_array[utt, col] = score
+    classify_template_ids[utt, col] = tid
+    classify_template_lengths[utt, col] = lengths[tid]
+    classify_locs[utt, col] = ws + pos - np.repeat(f0, n_ph)
     return classify_array, classify_locs, classify_template_lengths, classify_template_ids
 
 

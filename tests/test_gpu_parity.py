@@ -1196,3 +1196,44 @@ def test_edges2_random_vs_oracle(mods, oracle):
         assert np.array_equal(esp.magnitude_features(S, bl, sr, q, sm, dn, mag_spread_length=msl), want), trial
         assert np.array_equal(esp.magnitude_features_whole_block(S, bl, sr, q, sm, dn), want2), trial
     assert done > 30
+
+
+# ---- BASELINE config 5: the bank as a bf16 MFMA GEMM (comparison variants) ----------------------------------------
+@pytest.mark.parametrize("shape", [
+    dict(N=4, T=200, F=45, E=8, M=8, L=32),                                              # config-2 shape
+    dict(N=5, T=[200, 64, 31, 150, 200], F=45, E=8, M=64, L=[24 + (7 * m) % 25 for m in range(64)]),   # config-4 bank: 9 column groups
+    dict(N=3, T=[50, 1, 30], F=3, E=3, M=1, L=[5]),
+])
+def test_bf16_bank_variants(mods, oracle, shape):
+    """TSR_FAST | TSR_BF16 | TSR_W24 (bf16 hi + lo, f32 accumulate) stays within the 1e-4 bar; the single-limb
+    TSR_FAST | TSR_BF16 (weights rounded to 8 significant bits) is the parity-relaxed variant: its error is bounded
+    by the weight rounding, 2^-9 sum|set taps|."""
+    tsr_hip = mods[3]
+    from tsr_hip import synth
+    c = synth.corpus(515, **shape)
+    feats, offs = c["feats"], c["offsets"]
+    bank = tsr_hip.Bank(c["bank"])
+    exact = bank.score_all(feats, offs, flags=tsr_hip.TSR_EXACT)
+    se, ae = bank.score(feats, offs, flags=tsr_hip.TSR_EXACT)
+    mags = tsr_hip.Bank([(np.abs(W), 0.0) for W, _ in c["bank"]]).score_all(feats, offs)   # sum of |set taps| per window
+    x2 = bank.score_all(feats, offs, flags=tsr_hip.TSR_FAST | tsr_hip.TSR_BF16 | tsr_hip.TSR_W24)
+    assert rel_err(x2, exact) <= TOL
+    s2, a2 = bank.score(feats, offs, flags=tsr_hip.TSR_FAST | tsr_hip.TSR_BF16 | tsr_hip.TSR_W24)
+    assert rel_err(s2, se) <= TOL
+    x1 = bank.score_all(feats, offs, flags=tsr_hip.TSR_FAST | tsr_hip.TSR_BF16)
+    assert np.all(np.abs(x1.astype(np.float64) - exact) <= 2.0 ** -9 * mags + 1e-3 * np.maximum(np.abs(exact), 1.0) * 1e-1)
+    assert rel_err(x1, exact) <= 5e-3
+    if exact.shape[0] > 1:
+        top2 = np.sort(exact, axis=0)[-2:]
+        clear = (top2[1] - top2[0]) > TOL * np.maximum(np.abs(top2[1]), 1.0)
+        assert np.array_equal(a2[clear], ae[clear])
+
+
+def test_bf16_unsupported_geometry_falls_back_to_exact(mods, oracle):
+    tsr_hip = mods[3]
+    from tsr_hip import synth
+    c = synth.corpus(516, N=2, T=40, F=41, E=50, M=2, L=[8, 5])      # D = 2050 > 384 features
+    bank = tsr_hip.Bank(c["bank"])
+    a = bank.score(c["feats"], c["offsets"], flags=tsr_hip.TSR_FAST | tsr_hip.TSR_BF16)
+    b = bank.score(c["feats"], c["offsets"], flags=tsr_hip.TSR_EXACT)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

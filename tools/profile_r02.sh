@@ -1,0 +1,45 @@
+# Round-2 evidence (GPU box, repo root):  bash tools/profile_r02.sh [part ...]   parts: bench traffic sq c45
+# Kernel stats and counters always come from separate rocprofv3 runs (--pmc with --kernel-trace only).
+cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out && export TMPDIR=/tmp
+PARTS=${@:-bench traffic sq c45}
+kstats() { # tag, program args...
+  local tag=$1; shift
+  rm -rf gpurun_out/ks_$tag
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks_$tag -o $tag -- python3 "$@" > gpurun_out/ks_$tag.log 2>&1 || return 1
+  cp $(find gpurun_out/ks_$tag -name "*kernel_stats.csv" | head -1) gpurun_out/r02_${tag}_kernel_stats.csv
+  tail -2 gpurun_out/ks_$tag.log | cut -c1-400
+  head -6 gpurun_out/r02_${tag}_kernel_stats.csv | cut -c1-200
+}
+pmc() { # tag, counters, program args...
+  local tag=$1 ctr=$2; shift 2
+  rm -rf gpurun_out/pmc_$tag
+  timeout -k 10 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc_$tag -o $tag -- python3 "$@" > gpurun_out/pmc_$tag.log 2>&1 || return 1
+  python3 tools/pmc_summary.py gpurun_out/pmc_$tag > gpurun_out/r02_pmc_$tag.txt && cat gpurun_out/r02_pmc_$tag.txt
+}
+for part in $PARTS; do
+case $part in
+bench)
+  kstats bench_fast bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-modes --mode fast && \
+  kstats bench_fast24 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-modes --mode fast24 && \
+  kstats bench_exact bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-modes --mode exact || exit 1 ;;
+traffic)   # HBM bytes per launch on a working set of 16 corpus copies (1.2 GB >> 256 MiB of Infinity Cache)
+  pmc traffic_fetch FETCH_SIZE bench.py --steps 3 --warmup 1 --replicas 16 --no-cpu-baseline --no-modes --mode fast && \
+  pmc traffic_write WRITE_SIZE bench.py --steps 3 --warmup 1 --replicas 16 --no-cpu-baseline --no-modes --mode fast || exit 1 ;;
+sq)
+  pmc sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" bench.py --steps 3 --warmup 1 --replicas 16 --no-cpu-baseline --no-modes --mode fast && \
+  pmc sq2 "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM" bench.py --steps 3 --warmup 1 --replicas 16 --no-cpu-baseline --no-modes --mode fast || exit 1 ;;
+c45)
+  M45=${M45:-fast,fast24,exact}
+  timeout -k 10 300 python3 tools/time_config45.py $M45 4 5 > gpurun_out/r02_config45_timing.txt 2>&1 && cat gpurun_out/r02_config45_timing.txt && \
+  kstats c45 tools/time_config45.py $M45 4 2 && \
+  pmc c45_fetch FETCH_SIZE tools/time_config45.py $M45 4 1 && \
+  pmc c45_write WRITE_SIZE tools/time_config45.py $M45 4 1 && \
+  pmc c45_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" tools/time_config45.py $M45 4 1 || exit 1 ;;
+c45x)  # the same bank with the round-robin block mapping (column groups of a segment on different XCDs)
+  export TSR_XCD_MAP=0
+  timeout -k 10 300 python3 tools/time_config45.py fast 4 5 > gpurun_out/r02_config45_roundrobin_timing.txt 2>&1 && cat gpurun_out/r02_config45_roundrobin_timing.txt && \
+  pmc c45x_fetch FETCH_SIZE tools/time_config45.py fast 4 1 || exit 1
+  unset TSR_XCD_MAP ;;
+esac
+done
+echo "profile_r02 done: $PARTS"
