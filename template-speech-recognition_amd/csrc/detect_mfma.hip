@@ -10,6 +10,15 @@ TSR_FAST_EXTERN(7) TSR_FAST_EXTERN(8) TSR_FAST_EXTERN(9) TSR_FAST_EXTERN(10) TSR
 #undef TSR_FAST_EXTERN
 }  // namespace tsr_fast
 
+namespace tsr_fast {
+constexpr int kTap2MaxNKB = 23;  // (detect_mfma_tap2.inc)
+template <int NKB2> int launch_tap2(tsr_ctx *, const FastArgs &, int, size_t);
+#define TSR_TAP2_EXTERN(N) extern template int launch_tap2<N>(tsr_ctx *, const FastArgs &, int, size_t);
+TSR_TAP2_EXTERN(1) TSR_TAP2_EXTERN(3) TSR_TAP2_EXTERN(5) TSR_TAP2_EXTERN(7) TSR_TAP2_EXTERN(9) TSR_TAP2_EXTERN(11)
+TSR_TAP2_EXTERN(13) TSR_TAP2_EXTERN(15) TSR_TAP2_EXTERN(17) TSR_TAP2_EXTERN(19) TSR_TAP2_EXTERN(21) TSR_TAP2_EXTERN(23)
+#undef TSR_TAP2_EXTERN
+}  // namespace tsr_fast
+
 using namespace tsr_fast;
 
 namespace {
@@ -83,7 +92,8 @@ static void fast_bank_free_one(tsr_bank *bank, int which)
 
 void tsr_fast_bank_free(tsr_bank *bank)
 {
-    for (int k = 0; k < 4; ++k) fast_bank_free_one(bank, k);
+    for (int k = 0; k < 5; ++k) fast_bank_free_one(bank, k);
+    bank->tap2_unsupported = false;
 }
 
 static uint16_t bf16_rn(float x)  // round to nearest even (finite inputs)
@@ -105,24 +115,34 @@ static float bf16_value(uint16_t h)
 // weights; 3: bf16 hi + lo.  Built lazily, cached in bank->fast[kind].
 int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int kind)
 {
-    const bool bf = kind >= 2;
-    const int NL = bf ? kind - 1 : kind + 2;
+    const bool tap2 = kind == 4;   // two int8 limbs, two taps per column (detect_mfma_tap2.inc)
+    const bool bf = kind == 2 || kind == 3;
+    const int NL = tap2 ? 2 : (bf ? kind - 1 : kind + 2);
     const int M = bank->M;
     const int64_t D = bank->D;
+    const int64_t Dp = (D + 15) / 16 * 16;      // the resident row of a corpus with this D
+    if (tap2 && (Dp / 16 > kTap2MaxNKB || (Dp / 16) % 2 == 0)) {
+        tsr_set_error("TSR_FAST (tap pairs): resident rows of %lld bytes do not fit (need an odd number <= %d of 16-byte slots)",
+                      (long long)Dp, kTap2MaxNKB);
+        return TSR_ERR_UNSUPPORTED;
+    }
     if (bf && D > 16 * kBfSteps) {
         tsr_set_error("TSR_BF16: D=%lld exceeds the %d features of the bf16 variant", (long long)D, 16 * kBfSteps);
         return TSR_ERR_UNSUPPORTED;
     }
-    const int nkb_total = bf ? kBfSteps : (int)((D + 31) / 32);
+    const int nkb_total = tap2 ? (int)(Dp / 16) : (bf ? kBfSteps : (int)((D + 31) / 32));
     // Feature rows wider than one wave's register budget (kMaxNKB K-blocks) are split into
     // K-phases: each phase is a complete kernel pass over its own feature range with its own
     // register-stationary limbs; the phases' partial raw scores are summed by the epilogue.
     // (bf16: one pass of kBfSteps 16-feature steps, the kernel is instantiated for exactly that)
-    const int n_phase = bf ? 1 : (nkb_total + kMaxNKB - 1) / kMaxNKB;
-    const int NKB = bf ? kBfSteps : (nkb_total + n_phase - 1) / n_phase;
+    const int n_phase = (bf || tap2) ? 1 : (nkb_total + kMaxNKB - 1) / kMaxNKB;
+    const int NKB = (bf || tap2) ? nkb_total : (nkb_total + n_phase - 1) / n_phase;
     const int KS = 1;
-    const int CT = kWaves / KS;
-    const int64_t C = bank->sumL;
+    const int CT = tap2 ? 4 : kWaves / KS;       // tap pairs: both wave groups hold the same four column tiles
+    const int64_t K2 = 2 * Dp;                   // tap pairs: K runs over (tap b of the pair, byte of the resident row)
+    auto ncols = [&](int L) { return tap2 ? (L + 1) / 2 : L; };
+    int64_t C = 0;
+    for (int m = 0; m < M; ++m) C += ncols(bank->L[m]);
     const int n_coltiles = (int)((C + 31) / 32);
     const int G = (n_coltiles + CT - 1) / CT;
 
@@ -131,7 +151,7 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int kind)
     // NL = 2: q = rint(W * qmax / max|W|), qmax = min(127*256, (2^31-1) / (L_m * D)) so that the
     //         int32 ring cannot overflow even if every feature of every tap is set.
     std::vector<double> inv_scale(M);
-    std::vector<int8_t> limbs(bf ? 0 : (size_t)NL * C * D);      // [limb][column][d]
+    std::vector<int8_t> limbs(bf ? 0 : (size_t)NL * C * (tap2 ? K2 : D));   // [limb][column][d]  (tap pairs: [b Dp + d])
     std::vector<uint16_t> blimbs(bf ? (size_t)NL * C * D : 0);   // bf16: hi (and lo = rn(W - hi))
     std::vector<int32_t> col_tmpl((size_t)C), col_tau_v((size_t)C);
     {
@@ -161,7 +181,21 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int kind)
                 sc = ldexp(1.0, std::max(-60, std::min(e, 60)));
             }
             inv_scale[m] = 1.0 / sc;
-            for (int tau = 0; tau < bank->L[m]; ++tau) {
+            for (int a = 0; tap2 && a < ncols(bank->L[m]); ++a) {
+                const int64_t c = c0 + a;
+                col_tmpl[(size_t)c] = m;
+                col_tau_v[(size_t)c] = 2 * a;            // the pair's first tap: the column's rows belong to frame row - 2a
+                for (int b2 = 0; b2 < 2 && 2 * a + b2 < bank->L[m]; ++b2)
+                    for (int64_t d = 0; d < D; ++d) {
+                        int q = (int)llrint((double)w[(int64_t)(2 * a + b2) * D + d] * sc);
+                        for (int l = 0; l < NL; ++l) {
+                            int digit = (l == NL - 1) ? q : ((q + 128) & 255) - 128;
+                            limbs[((size_t)l * C + c) * K2 + b2 * Dp + d] = (int8_t)digit;
+                            q = (q - digit) >> 8;
+                        }
+                    }
+            }
+            for (int tau = 0; !tap2 && tau < bank->L[m]; ++tau) {
                 const int64_t c = c0 + tau;
                 col_tmpl[(size_t)c] = m;
                 col_tau_v[(size_t)c] = tau;
@@ -181,7 +215,7 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int kind)
                 }
             }
             woff += n;
-            c0 += bank->L[m];
+            c0 += ncols(bank->L[m]);
         }
     }
     // ---- column groups -> fragment slots ------------------------------------------------------
@@ -257,6 +291,10 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int kind)
                             continue;
                         }
                         const int64_t k0 = ((int64_t)ph * NKB + kb) * 32 + 16 * (lane >> 5);
+                        if (tap2) {
+                            for (int e = 0; e < 16; ++e) dst[e] = limbs[((size_t)l * C + c) * K2 + k0 + e];
+                            continue;
+                        }
                         for (int e = 0; e < 16; ++e)
                             if (k0 + e < D) dst[e] = limbs[((size_t)l * C + c) * D + k0 + e];
                     }
@@ -341,6 +379,122 @@ static int build_plan(tsr_ctx *ctx, tsr_corpus *cp, int nseg, int Lmax)
     TSR_HIP(hipStreamSynchronize(ctx->stream));
     cp->plan_key = key;
     cp->plan_nseg = nseg;
+    return TSR_OK;
+}
+
+// TSR_FAST on narrow rows: tap pairs folded into K (detect_mfma_tap2.inc).  TSR_ERR_UNSUPPORTED when the
+// geometry does not fit; the caller then takes the interleaved kernel.
+int tsr_launch_tap2_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, float *d_scores, int32_t *d_ids, float *d_all)
+{
+    const FastBank *fb = static_cast<const FastBank *>(bank->fast[4]);
+    if (!fb) return TSR_ERR_UNSUPPORTED;
+    const int64_t P = cp->P;
+    if (P == 0) return TSR_OK;
+    const int Dp = cp->Dp;
+    if (Dp != fb->NKB * 16 || fb->NKB > kTap2MaxNKB || (fb->NKB & 1) == 0 || fb->CT != 4 || fb->n_phase != 1) {
+        tsr_set_error("TSR_FAST (tap pairs): corpus rows of %d bytes do not match the bank's %d K-blocks", Dp, fb->NKB);
+        return TSR_ERR_UNSUPPORTED;
+    }
+    const int lag0 = (bank->Lmax - 1 + 31) / 32;
+    int ring = 32;
+    while (ring < 32 * (lag0 + 13)) ring *= 2;
+    const int NBT = 6;
+    const size_t frames_b = ((size_t)NBT * 32 * Dp + Dp + 48 + 15) & ~(size_t)15;
+    const size_t lds = frames_b + (size_t)kMaxSlots * sizeof(SlotMeta) + (size_t)(ring + 64) * 4 + (size_t)ring * 8 +
+                       (size_t)(fb->max_slots + 1) * (ring + 33) * 4 + 64;
+    if (lds > 160 * 1024) {
+        tsr_set_error("TSR_FAST (tap pairs): Lmax=%d needs %zu bytes of LDS", bank->Lmax, lds);
+        return TSR_ERR_UNSUPPORTED;
+    }
+    int nseg = std::max(1, ctx->cus / fb->G);
+    const int64_t min_rows = 128;
+    nseg = (int)std::max<int64_t>(1, std::min<int64_t>(nseg, (P + min_rows - 1) / min_rows));
+    int spx = 0;
+    if (fb->G > 1 && fb->G <= 2 * (ctx->cus / 8)) {
+        const char *e = getenv("TSR_XCD_MAP");
+        const int want = (2 * (ctx->cus / 8)) / fb->G;
+        if (!(e && e[0] == '0') && want >= 1 && (int64_t)8 * want * min_rows * 2 <= P) {
+            spx = want;
+            nseg = 8 * spx;
+        }
+    }
+    TSR_TRY(build_plan(ctx, cp, nseg, bank->Lmax));
+    const bool fragments = fb->G > 1;
+    void *raw_frag = nullptr;
+    if (fragments) TSR_TRY(tsr_scratch(ctx, 0, (size_t)fb->n_frag * P * sizeof(float), &raw_frag));
+    const int grid = nseg * fb->G;
+    FastArgs a;
+    memset(&a, 0, sizeof a);
+    a.X = cp->d_feats;
+    a.Dp = Dp;
+    a.SB = Dp;
+    a.src_slots = Dp >> 4;
+    a.tile_bytes = 32 * Dp;
+    a.G = fb->G;
+    a.CT = fb->CT;
+    a.KS = 1;
+    a.nseg = nseg;
+    a.spx = spx;
+    a.seg = cp->d_plan;
+    a.Wl = fb->d_Wl;
+    a.col_slot = fb->d_col_slot;
+    a.col_tau = fb->d_col_tau;
+    a.slots = fb->d_slots;
+    a.g_nslots = fb->d_g_nslots;
+    a.utt_end = cp->d_utt_end;
+    a.P = P;
+    a.ring = ring;
+    a.lag = lag0;
+    a.lmax1 = bank->Lmax - 1;
+    unsigned long long *d_dbg = nullptr;
+#ifdef TSR_STAMP
+    TSR_HIP(hipMalloc(reinterpret_cast<void **>(&d_dbg), (size_t)grid * kWaves * 6 * 8));
+    TSR_HIP(hipMemsetAsync(d_dbg, 0, (size_t)grid * kWaves * 6 * 8, ctx->stream));
+#endif
+    a.dbg = d_dbg;
+    if (fragments) {
+        a.raw_frag = (float *)raw_frag;
+    } else {
+        a.scores = d_scores;
+        a.ids = d_ids;
+        a.all = d_all;
+    }
+    int s;
+    switch (fb->NKB) {
+    case 1: s = launch_tap2<1>(ctx, a, grid, lds); break;
+    case 3: s = launch_tap2<3>(ctx, a, grid, lds); break;
+    case 5: s = launch_tap2<5>(ctx, a, grid, lds); break;
+    case 7: s = launch_tap2<7>(ctx, a, grid, lds); break;
+    case 9: s = launch_tap2<9>(ctx, a, grid, lds); break;
+    case 11: s = launch_tap2<11>(ctx, a, grid, lds); break;
+    case 13: s = launch_tap2<13>(ctx, a, grid, lds); break;
+    case 15: s = launch_tap2<15>(ctx, a, grid, lds); break;
+    case 17: s = launch_tap2<17>(ctx, a, grid, lds); break;
+    case 19: s = launch_tap2<19>(ctx, a, grid, lds); break;
+    case 21: s = launch_tap2<21>(ctx, a, grid, lds); break;
+    default: s = launch_tap2<23>(ctx, a, grid, lds); break;
+    }
+    TSR_TRY(s);
+#ifdef TSR_STAMP
+    if (const char *path = getenv("TSR_STAMP_OUT")) {
+        std::vector<unsigned long long> h((size_t)grid * kWaves * 6);
+        TSR_HIP(hipStreamSynchronize(ctx->stream));
+        TSR_HIP(hipMemcpy(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE *fp = fopen(path, "w")) {
+            for (size_t w = 0; w < (size_t)grid * kWaves; ++w)
+                fprintf(fp, "%zu %zu %llu %llu %llu %llu %llu %llu\n", w / kWaves, w % kWaves, h[w * 6], h[w * 6 + 1],
+                        h[w * 6 + 2], h[w * 6 + 3], h[w * 6 + 4], h[w * 6 + 5]);
+            fclose(fp);
+        }
+    }
+    (void)hipFree(d_dbg);
+#endif
+    if (fragments) {
+        hipLaunchKernelGGL(frag_epilogue_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const float *)raw_frag, P, bank->M, fb->d_frag_ptr, fb->d_frag_idx, bank->d_L, bank->d_cf,
+                           cp->d_utt_end, d_scores, d_ids, d_all);
+        TSR_HIP(hipGetLastError());
+    }
     return TSR_OK;
 }
 

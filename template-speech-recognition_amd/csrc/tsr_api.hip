@@ -474,6 +474,19 @@ static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp,
         // "at least 16-bit" bound of include/tsr.h) the bank takes three limbs and the int64 ring.
         if ((int64_t)bank->Lmax * bank->D > TSR_FAST_W24_ABOVE_TAPS) flags |= TSR_W24;
     }
+    if (flags == TSR_FAST && !bank->tap2_unsupported) {
+        // TSR_FASTK=tap2 (read per launch: A/B measurements inside one process): two limbs on narrow feature rows
+        // with tap pairs folded into K (detect_mfma_tap2.inc).  Parity-green and level with the interleaved
+        // kernel on config 2 (34.6 vs 34.9 us), slower on wide banks, hence not the default.
+        const char *e = getenv("TSR_FASTK");
+        if (e && e[0] == 't') {
+            tsr_bank *mb = const_cast<tsr_bank *>(bank);
+            int sb = bank->fast[4] ? TSR_OK : tsr_fast_bank_build(ctx, mb, 4);
+            if (sb == TSR_OK) sb = tsr_launch_tap2_bank(ctx, bank, cp, d_all ? nullptr : cp->d_scores, d_all ? nullptr : cp->d_ids, d_all);
+            if (sb != TSR_ERR_UNSUPPORTED) return sb;
+            if (!bank->fast[4]) mb->tap2_unsupported = true;   // geometry never fits: do not try again
+        }
+    }
     if (flags & TSR_FAST) {
         const int kind = ((flags & TSR_BF16) ? 2 : 0) + ((flags & TSR_W24) ? 1 : 0);
         if (!bank->fast[kind]) {

@@ -99,8 +99,10 @@ struct tsr_bank {
     int32_t *d_gx_L = nullptr;
     int32_t *d_L = nullptr;          // [M]
     float *d_cf = nullptr;           // [M]  f32(c_m)
-    // device, fast path (built lazily by detect_mfma.hip): [0] two int8 limbs, [1] three, [2] bf16, [3] bf16 hi + lo
-    void *fast[4] = {nullptr, nullptr, nullptr, nullptr};
+    // device, fast path (built lazily by detect_mfma.hip): [0] two int8 limbs, [1] three, [2] bf16, [3] bf16 hi + lo,
+    // [4] two int8 limbs with two taps folded into K (tap2_bank_kernel, narrow feature rows)
+    void *fast[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool tap2_unsupported = false;   // the kind-4 build was tried and the geometry does not fit
 };
 
 struct tsr_corpus {
@@ -205,6 +207,7 @@ int tsr_launch_code_parts_mfma(tsr_ctx *ctx, const tsr_parts *p, const uint8_t *
 int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int kind);  // kind: index into tsr_bank::fast
 int tsr_corpus_bf16_copy(tsr_ctx *ctx, struct tsr_corpus *cp);
 void tsr_fast_bank_free(tsr_bank *bank);
+int tsr_launch_tap2_bank(tsr_ctx *ctx, const tsr_bank *bank, struct tsr_corpus *cp, float *d_scores, int32_t *d_ids, float *d_all);
 int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *corpus, int flags,
                          float *d_scores, int32_t *d_ids, float *d_all);
 // parts.hip

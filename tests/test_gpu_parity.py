@@ -1237,3 +1237,43 @@ def test_bf16_unsupported_geometry_falls_back_to_exact(mods, oracle):
     a = bank.score(c["feats"], c["offsets"], flags=tsr_hip.TSR_FAST | tsr_hip.TSR_BF16)
     b = bank.score(c["feats"], c["offsets"], flags=tsr_hip.TSR_EXACT)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_tap_pair_kernel_parity(mods, oracle):
+    """TSR_FASTK=tap2 selects the two-taps-in-K, alternating-segment variant of the two-limb bank pass
+    (csrc/detect_mfma_tap2.inc; an experiment kept for A/B measurements): the same exact integer sums as the default
+    kernel -- identical scores and ids at the benchmark's size and on ragged geometry, one float32 rounding apart when
+    there are several column groups."""
+    import os
+    tsr_hip = mods[3]
+    from tsr_hip import synth
+    rng = np.random.default_rng(77)
+    T = rng.integers(1, 301, size=150)
+    T[::17] = 0
+    cases = [synth.corpus(2, N=1000, T=200, F=45, E=8, M=8, L=32),
+             synth.corpus(3, N=150, T=T, F=45, E=8, M=8, L=[20, 24, 28, 32, 36, 40, 44, 47]),
+             synth.corpus(4, N=40, T=200, F=45, E=8, M=64, L=[24 + (7 * m) % 25 for m in range(64)]),
+             synth.corpus(5, N=3, T=[50, 1, 30], F=3, E=3, M=1, L=[5])]
+    for c in cases:
+        P = int(c["offsets"][-1])
+        bank = tsr_hip.Bank(c["bank"])
+        dc = tsr_hip.Corpus(c["feats"].reshape(P, -1), c["offsets"])
+        dc.score(bank, tsr_hip.TSR_FAST)
+        want = dc.download()
+        want_all = dc.score_all(bank, tsr_hip.TSR_FAST)
+        os.environ["TSR_FASTK"] = "tap2"
+        try:
+            dc.score(bank, tsr_hip.TSR_FAST)
+            got = dc.download()
+            got_all = dc.score_all(bank, tsr_hip.TSR_FAST)
+        finally:
+            del os.environ["TSR_FASTK"]
+        if bank.M <= 8:
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+            assert np.array_equal(got_all, want_all)
+        else:
+            # several column groups: a template cut at a group boundary is the float sum of two exact partial
+            # sums, and the two kernels cut at different columns -- one float32 rounding apart
+            assert rel_err(got[0], want[0]) <= 1e-6 and rel_err(got_all, want_all) <= 1e-6
+        dc.score(bank, tsr_hip.TSR_EXACT)
+        assert rel_err(got[0], dc.download()[0]) <= TOL
