@@ -448,8 +448,8 @@ int tsr_launch_tap2_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, flo
     a.lmax1 = bank->Lmax - 1;
     unsigned long long *d_dbg = nullptr;
 #ifdef TSR_STAMP
-    TSR_HIP(hipMalloc(reinterpret_cast<void **>(&d_dbg), (size_t)grid * kWaves * 6 * 8));
-    TSR_HIP(hipMemsetAsync(d_dbg, 0, (size_t)grid * kWaves * 6 * 8, ctx->stream));
+    TSR_HIP(hipMalloc(reinterpret_cast<void **>(&d_dbg), (size_t)grid * kWaves * 16 * 8));
+    TSR_HIP(hipMemsetAsync(d_dbg, 0, (size_t)grid * kWaves * 16 * 8, ctx->stream));
 #endif
     a.dbg = d_dbg;
     if (fragments) {
@@ -477,13 +477,16 @@ int tsr_launch_tap2_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, flo
     TSR_TRY(s);
 #ifdef TSR_STAMP
     if (const char *path = getenv("TSR_STAMP_OUT")) {
-        std::vector<unsigned long long> h((size_t)grid * kWaves * 6);
+        std::vector<unsigned long long> h((size_t)grid * kWaves * 16);
         TSR_HIP(hipStreamSynchronize(ctx->stream));
         TSR_HIP(hipMemcpy(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost));
         if (FILE *fp = fopen(path, "w")) {
             for (size_t w = 0; w < (size_t)grid * kWaves; ++w)
-                fprintf(fp, "%zu %zu %llu %llu %llu %llu %llu %llu\n", w / kWaves, w % kWaves, h[w * 6], h[w * 6 + 1],
-                        h[w * 6 + 2], h[w * 6 + 3], h[w * 6 + 4], h[w * 6 + 5]);
+            {
+                fprintf(fp, "%zu %zu", w / kWaves, w % kWaves);
+                for (int i = 0; i < 16; ++i) fprintf(fp, " %llu", h[w * 16 + i]);
+                fprintf(fp, "\n");
+            }
             fclose(fp);
         }
     }
