@@ -1,0 +1,196 @@
+// detect_exact_mfma.hip -- TSR_EXACT (the bit-identical path) on the matrix cores of gfx950.
+//
+// The reference adds a window's taps one at a time, in f32, in the order tau -> frequency -> part
+// (compute_likelihood_linear_filter.pyx:162-175); detect_exact.hip reproduces that with one lane per window and
+// one v_fmac per tap and template.  v_mfma_f32_16x16x4_f32 does the same arithmetic 1024 taps at a time:
+// D[i][j] = C[i][j] + sum_k A[i][k] B[k][j] is evaluated as the fmaf chain k = 0, 1, 2, 3 (ascending, one
+// rounding per step; tools/ubench/mfma_f32_chain.hip: 0 of 256 outputs differ from fmaf over 2048-step chains),
+// and consecutive MFMAs on the same accumulator continue the chain.  So with
+//     row    i      = window at frame 32 T + 2 i            (16 windows at a stride of two frames)
+//     column j      = (template m = j & 7, replica r = j >> 3)
+//     K      step   = (tap row tau' = 0 .. L, features 4 n .. 4 n + 3)
+//     A[i][k]       = X[32 T + 2 i + tau'][4 n + k]                      (0.0 or 1.0)
+//     B[k][(m, r)]  = W_m[tau' - r][4 n + k]   (0 outside 0 <= tau' - r < L_m)
+// column (m, r) of row i walks exactly the taps of the window at frame 32 T + 2 i + r in the reference's order
+// (the zero products in front of / behind it leave the sum untouched: s + (+-0) = s), all sixteen columns of the
+// instruction carry work for a group of eight templates, and one tile of accumulators covers 32 frames.
+//
+// Operand feed.  B fragments are precomputed per bank ([tau'][n / 4][lane] float4, one coalesced 16-byte load
+// per lane and four K-steps).  A fragments never exist as data: the frames are kept as BIT PLANES
+//     plane[q][b][n]  (64 bits)  bit 16 k + i  =  X[32 b + 2 i + q][4 n + k]
+// (exact_planes_kernel, built once per resident corpus), i.e. for frames of one parity the lane mask of an
+// aligned tile is one 64-bit word; a tile that starts s rows into a block is a funnel of two neighbouring
+// words (five scalar instructions), and the operand register is one v_cndmask_b32 (mask ? 1.0 : 0.0).  The
+// masks arrive by scalar loads, so the vector unit issues one instruction per MFMA and there is no LDS.
+//
+// Roofline: matrix-core bound.  P/32 tiles x (L+1) Dp/4 MFMAs x ceil(M/8) groups, 32 cycles each.
+#include "tsr_internal.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kMaxNT = 3;       // tiles (of 32 frames) a wave carries through one pass over the taps
+constexpr int kWavesPerCU = 12; // three per SIMD
+
+// One wave per 64 frames (two blocks).  Lane l = 16 c + i reads row 32 (2 w + (c >> 1)) + 2 i + (c & 1), so that the
+// ballot of feature k is four 16-bit fields (block half, parity) and lane c < 4 assembles word c from the four
+// ballots of a dword.
+__global__ __launch_bounds__(256) void exact_planes_kernel(const uint8_t *__restrict__ X, int64_t P, int Dp, int NK, int64_t nb,
+                                                            unsigned long long *__restrict__ planes)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t w = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (2 * w >= nb) return;  // (whole wave)
+    const int i = lane & 15, c = lane >> 4;
+    const int64_t row = 32 * (2 * w + (c >> 1)) + 2 * i + (c & 1);
+    const bool ok = row < P;
+    const uint4 *xr = reinterpret_cast<const uint4 *>(X + row * Dp);
+    const int sh = 16 * (lane & 3);
+    const int q = lane & 1;
+    const int64_t b = 2 * w + ((lane & 3) >> 1);
+    unsigned long long *dst = planes + ((int64_t)q * nb + b) * NK;
+    const bool wr = lane < 4 && b < nb;
+    for (int n4 = 0; n4 < (NK >> 2); ++n4) {
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (ok) x = xr[n4];
+        const uint32_t dw[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            unsigned long long res = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned long long bal = __ballot((dw[u] >> (8 * k)) & 0xffu);
+                res |= ((bal >> sh) & 0xffffull) << (16 * k);
+            }
+            if (wr) dst[4 * n4 + u] = res;
+        }
+    }
+}
+
+__device__ __forceinline__ float mask_to_operand(unsigned long long mask)
+{
+    // (an ordinary VALU instruction to the compiler -- v_cndmask_b32 with the scalar pair as its mask -- so that its
+    // hazard recognizer keeps the distance a matrix instruction needs behind the write of its operand; the same
+    // instruction issued through inline asm gave wrong sums)
+    return __builtin_amdgcn_inverse_ballot_w64(mask) ? 1.0f : 0.0f;
+}
+
+// NT tiles T0 .. T0+NT-1 of one template group through all taps; raw scores of the group's templates out.
+template <int NT>
+__device__ __forceinline__ void exact_run(const unsigned long long *__restrict__ planes, int64_t nb, int NK,
+                                          const f32x4 *__restrict__ wg, int Lg1, int64_t T0, int lane, float *__restrict__ raw_g,
+                                          int64_t P, int Mg)
+{
+    const int NK4 = NK >> 2;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    const f32x4 *wp = wg + lane;
+    for (int tp = 0; tp < Lg1; ++tp) {
+        const int s = (tp >> 1) & 15;
+        const unsigned long long lo = 0x0001000100010001ull * (unsigned long long)(0xffffu >> s);
+        const unsigned long long *st = planes + ((int64_t)(tp & 1) * nb + T0 + (tp >> 5)) * NK;
+        for (int n4 = 0; n4 < NK4; ++n4) {
+            const f32x4 bf = *wp;
+            wp += 64;
+            unsigned long long Q[NT + 1][4];
+#pragma unroll
+            for (int j = 0; j <= NT; ++j)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) Q[j][u] = st[(int64_t)j * NK + 4 * n4 + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const unsigned long long mask = ((Q[t][u] >> s) & lo) | ((Q[t + 1][u] << (16 - s)) & ~lo);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(mask_to_operand(mask), bf[u], acc[t], 0, 0, 0);
+                }
+        }
+    }
+    // lane l holds rows i = 4 (l / 16) + r of column j = l % 16: template j & 7 at frame 32 T + 2 i + (j >> 3)
+    const int j = lane & 15;
+    const int m = j & 7;
+    if (m < Mg) {
+        float *dst = raw_g + (int64_t)m * P;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t p = 32 * (T0 + t) + 2 * (4 * (lane >> 4) + r) + (j >> 3);
+                if (p < P) dst[p] = acc[t][r];
+            }
+    }
+}
+
+// Units u = g * nTiles + T are dealt to the waves in contiguous, equally long ranges; a wave walks its range in
+// runs of up to kMaxNT tiles of one group.
+__global__ __launch_bounds__(256) void exact_mfma_kernel(const unsigned long long *__restrict__ planes, int64_t nb, int NK,
+                                                         const f32x4 *__restrict__ wmf, const int64_t *__restrict__ gm_off,
+                                                         const int32_t *__restrict__ gx_L, int64_t nTiles, int64_t U, int64_t nW,
+                                                         int M, int64_t P, float *__restrict__ raw)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t w = __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6));
+    if (w >= nW) return;
+    int64_t u = (U * w) / nW;
+    const int64_t hi = (U * (w + 1)) / nW;
+    while (u < hi) {
+        const int64_t g = u / nTiles, T0 = u - g * nTiles;
+        const int nt = (int)min((int64_t)kMaxNT, min(hi - u, nTiles - T0));
+        const f32x4 *wg = wmf + gm_off[g];
+        const int Lg1 = gx_L[g] + 1;
+        float *raw_g = raw + g * TSR_MG * P;
+        const int Mg = min(TSR_MG, M - (int)g * TSR_MG);
+        if (nt == 3)
+            exact_run<3>(planes, nb, NK, wg, Lg1, T0, lane, raw_g, P, Mg);
+        else if (nt == 2)
+            exact_run<2>(planes, nb, NK, wg, Lg1, T0, lane, raw_g, P, Mg);
+        else
+            exact_run<1>(planes, nb, NK, wg, Lg1, T0, lane, raw_g, P, Mg);
+        u += nt;
+    }
+}
+
+}  // namespace
+
+// Bit planes of a resident corpus with room for tap rows up to Lmax (rebuilt larger when a longer bank comes).
+static int ensure_planes(tsr_ctx *ctx, tsr_corpus *cp, int Lmax)
+{
+    const int64_t nTiles = (cp->P + 31) / 32;
+    const int64_t nb = nTiles + ((Lmax + 1) >> 5) + kMaxNT + 2;
+    if (cp->d_planes && cp->planes_nb >= nb) return TSR_OK;
+    if (cp->d_planes) {
+        TSR_HIP(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(cp->d_planes);
+        cp->d_planes = nullptr;
+    }
+    const int64_t nb2 = nb + 8;  // (a little headroom for the next, slightly longer bank)
+    const int NK = cp->Dp / 4;
+    TSR_HIP(hipMalloc(reinterpret_cast<void **>(&cp->d_planes), (size_t)2 * nb2 * NK * 8));
+    cp->planes_nb = nb2;
+    const int64_t waves = (nb2 + 1) / 2;
+    hipLaunchKernelGGL(exact_planes_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ctx->stream, cp->d_feats, cp->P, cp->Dp, NK,
+                       nb2, reinterpret_cast<unsigned long long *>(cp->d_planes));
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+
+// TSR_ERR_UNSUPPORTED: the bank has no matrix-core form (weights that are not finite or so small that partial sums
+// could be subnormal); the caller then takes the vector kernel.
+int tsr_launch_exact_bank_mfma(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, float *d_raw)
+{
+    if (!bank->d_Wm || cp->Dp != bank->wm_Dp) return TSR_ERR_UNSUPPORTED;
+    if (cp->P == 0) return TSR_OK;
+    TSR_TRY(ensure_planes(ctx, cp, bank->Lmax));
+    const int64_t nTiles = (cp->P + 31) / 32;
+    const int64_t U = nTiles * bank->n_groups;
+    const int64_t slots = (int64_t)kWavesPerCU * ctx->cus;
+    // as many waves as the chip holds at three per SIMD, but none with less than one tile
+    const int64_t nW = std::max<int64_t>(1, std::min<int64_t>(slots, U));
+    const unsigned grid = (unsigned)((nW + 3) / 4);
+    hipLaunchKernelGGL(exact_mfma_kernel, dim3(grid), dim3(256), 0, ctx->stream, reinterpret_cast<const unsigned long long *>(cp->d_planes),
+                       cp->planes_nb, cp->Dp / 4, reinterpret_cast<const f32x4 *>(bank->d_Wm), bank->d_gm_off, bank->d_gx_L, nTiles, U, nW,
+                       bank->M, cp->P, d_raw);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}

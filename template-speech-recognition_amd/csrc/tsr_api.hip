@@ -3,6 +3,7 @@
 // arithmetic lives in detect_exact.hip / detect_mfma.hip / parts.hip.
 #include <dlfcn.h>
 #include <math.h>
+#include <cmath>
 #include <stdarg.h>
 
 #include <algorithm>
@@ -234,16 +235,49 @@ static int bank_build_exact(tsr_ctx *ctx, tsr_bank *b)
     }
     std::vector<float> cf(M);
     for (int m = 0; m < M; ++m) cf[m] = (float)b->c[m];
+    // matrix-core form of the same chains (detect_exact_mfma.hip): column j = (template j & 7, replica j >> 3) of
+    // K-step (tau', features 4 n .. 4 n + 3) holds W_m[tau' - replica][4 n + k]; lane = 16 k + j, four K-steps per
+    // float4.  Only for banks whose sums can never be subnormal and whose weights are finite (the matrix cores are
+    // not trusted with either): every non-zero |w| >= 2^-100 makes every partial sum a multiple of 2^-123.
+    bool mfma_ok = true;
+    for (float w : b->W_cat) mfma_ok = mfma_ok && std::isfinite(w) && (w == 0.0f || std::fabs(w) >= 0x1p-100f);
+    const int Dp = (int)((D + 15) / 16 * 16), NK4 = Dp / 16;
+    std::vector<int64_t> gm_off(b->n_groups, 0);
+    std::vector<float> Wm;
+    if (mfma_ok) {
+        int64_t total4 = 0;
+        for (int g = 0; g < b->n_groups; ++g) {
+            gm_off[g] = total4;
+            total4 += (int64_t)(b->gx_L[g] + 1) * NK4 * 64;
+        }
+        Wm.assign((size_t)(total4 + 64) * 4, 0.0f);  // (+ one fragment: the kernel's last load may be a step ahead)
+        std::vector<int64_t> wstart(M + 1, 0);
+        for (int m = 0; m < M; ++m) wstart[m + 1] = wstart[m] + (int64_t)b->L[m] * D;
+        for (int g = 0; g < b->n_groups; ++g)
+            for (int tp = 0; tp <= b->gx_L[g]; ++tp)
+                for (int n4 = 0; n4 < NK4; ++n4)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int k = lane >> 4, j = lane & 15, m = g * TSR_MG + (j & 7), tau = tp - (j >> 3);
+                        if (m >= M || tau < 0 || tau >= b->L[m]) continue;
+                        float *dst = Wm.data() + (size_t)(gm_off[g] + ((int64_t)tp * NK4 + n4) * 64 + lane) * 4;
+                        for (int u = 0; u < 4; ++u) {
+                            const int64_t d = 16 * n4 + 4 * u + k;
+                            if (d < D) dst[u] = b->W_cat[(size_t)(wstart[m] + (int64_t)tau * D + d)];
+                        }
+                    }
+    }
     // new device forms first; the bank's pointers change only when all of them exist, so a failed
     // (re)build leaves the old, self-consistent bank behind
-    float *n_Wx = nullptr, *n_cf = nullptr;
-    int64_t *n_off = nullptr;
+    float *n_Wx = nullptr, *n_cf = nullptr, *n_Wm = nullptr;
+    int64_t *n_off = nullptr, *n_gm = nullptr;
     int32_t *n_gL = nullptr, *n_L = nullptr;
     int s = dev_upload(ctx, &n_Wx, Wx.data(), Wx.size());
     if (s == TSR_OK) s = dev_upload(ctx, &n_off, b->gx_off.data(), b->gx_off.size());
     if (s == TSR_OK) s = dev_upload(ctx, &n_gL, b->gx_L.data(), b->gx_L.size());
     if (s == TSR_OK) s = dev_upload(ctx, &n_L, b->L.data(), b->L.size());
     if (s == TSR_OK) s = dev_upload(ctx, &n_cf, cf.data(), cf.size());
+    if (s == TSR_OK && mfma_ok) s = dev_upload(ctx, &n_Wm, Wm.data(), Wm.size());
+    if (s == TSR_OK && mfma_ok) s = dev_upload(ctx, &n_gm, gm_off.data(), gm_off.size());
     if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {  // host staging vectors die here
         tsr_set_error("bank upload failed");
         s = TSR_ERR_HIP;
@@ -254,8 +288,15 @@ static int bank_build_exact(tsr_ctx *ctx, tsr_bank *b)
         dev_free(n_gL);
         dev_free(n_L);
         dev_free(n_cf);
+        dev_free(n_Wm);
+        dev_free(n_gm);
         return s;
     }
+    dev_free(b->d_Wm);
+    dev_free(b->d_gm_off);
+    b->d_Wm = n_Wm;
+    b->d_gm_off = n_gm;
+    b->wm_Dp = Dp;
     dev_free(b->d_Wx);
     dev_free(b->d_gx_off);
     dev_free(b->d_gx_L);
@@ -324,6 +365,8 @@ TSR_API int tsr_bank_destroy(tsr_bank *b)
     (void)hipDeviceSynchronize();
     tsr_fast_bank_free(b);
     dev_free(b->d_Wx);
+    dev_free(b->d_Wm);
+    dev_free(b->d_gm_off);
     dev_free(b->d_gx_off);
     dev_free(b->d_gx_L);
     dev_free(b->d_L);
@@ -442,6 +485,7 @@ TSR_API int tsr_corpus_destroy(tsr_corpus *cp)
     dev_free(cp->d_plan);
     dev_free(cp->d_aff);
     dev_free(cp->d_feats_bf16);
+    dev_free(cp->d_planes);
     delete cp;
     return TSR_OK;
 }
@@ -500,7 +544,13 @@ static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp,
     }
     void *raw = nullptr;
     TSR_TRY(tsr_scratch(ctx, SLOT_RAW, (size_t)bank->M * cp->P * sizeof(float), &raw));
-    TSR_TRY(tsr_launch_exact_bank(ctx, bank, cp->d_feats, cp->P, cp->Dp, (float *)raw));
+    // the reference's sums bit for bit: on the matrix cores where the bank has that form (TSR_EXACTK=valu keeps the
+    // vector kernel, for A/B measurements; read per launch), otherwise one lane per window
+    int se = TSR_ERR_UNSUPPORTED;
+    const char *ek = getenv("TSR_EXACTK");
+    if (!(ek && ek[0] == 'v')) se = tsr_launch_exact_bank_mfma(ctx, bank, cp, (float *)raw);
+    if (se == TSR_ERR_UNSUPPORTED) se = tsr_launch_exact_bank(ctx, bank, cp->d_feats, cp->P, cp->Dp, (float *)raw);
+    TSR_TRY(se);
     return tsr_launch_bank_epilogue(ctx, bank, (const float *)raw, cp->P, cp->d_utt_end, flags,
                                     d_all ? nullptr : cp->d_scores, d_all ? nullptr : cp->d_ids, d_all);
 }

@@ -99,6 +99,11 @@ struct tsr_bank {
     int32_t *d_gx_L = nullptr;
     int32_t *d_L = nullptr;          // [M]
     float *d_cf = nullptr;           // [M]  f32(c_m)
+    // exact path on the matrix cores (detect_exact_mfma.hip): B fragments [g][tau' = 0..Lg][Dp/16][lane] float4;
+    // absent (null) when a weight is not finite or small enough for subnormal partial sums
+    float *d_Wm = nullptr;
+    int64_t *d_gm_off = nullptr;     // float4 offset of group g in d_Wm
+    int wm_Dp = 0;                   // resident row stride the fragments were laid out for
     // device, fast path (built lazily by detect_mfma.hip): [0] two int8 limbs, [1] three, [2] bf16, [3] bf16 hi + lo,
     // [4] two int8 limbs with two taps folded into K (tap2_bank_kernel, narrow feature rows)
     void *fast[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -121,6 +126,8 @@ struct tsr_corpus {
     int plan_key = 0;                // (segments, Lmax) the plan was built for
     int plan_nseg = 0;
     int32_t *d_plan = nullptr;       // [3][nseg]: first output, end of outputs, end of rows
+    void *d_planes = nullptr;        // bit planes of the frames (detect_exact_mfma.hip), built on first use by TSR_EXACT
+    int64_t planes_nb = 0;           // blocks of 32 frames per parity the planes cover
     uint16_t *d_feats_bf16 = nullptr; // bf16 copy of the frames (rows of bf16_stride bytes), built on first use by TSR_BF16
     int bf16_stride = 0;
     // Bernoulli mixture: the posterior component probabilities the latest E-step left on the device
@@ -147,6 +154,7 @@ struct tsr_parts {
 
 // ---- kernels' host entry points (device pointers, enqueue on ctx->stream) -----
 // detect_exact.hip
+int tsr_launch_exact_bank_mfma(tsr_ctx *ctx, const tsr_bank *bank, struct tsr_corpus *cp, float *d_raw);
 int tsr_launch_exact_bank(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *d_feats, int64_t P,
                           int Dp, float *d_raw /*[M][P]*/);
 int tsr_launch_corpus_pack(tsr_ctx *ctx, const uint8_t *d_src, int64_t P, int D, int Dp,
