@@ -17,11 +17,15 @@
 //
 // Operand feed.  B fragments are precomputed per bank ([tau'][n / 4][lane] float4, one coalesced 16-byte load
 // per lane and four K-steps).  A fragments never exist as data: the frames are kept as BIT PLANES
-//     plane[q][b][n]  (64 bits)  bit 16 k + i  =  X[32 b + 2 i + q][4 n + k]
+//     plane[q][n / 4][b][n % 4]  (64 bits)  bit 16 k + i  =  X[32 b + 2 i + q][4 n + k]
 // (exact_planes_kernel, built once per resident corpus), i.e. for frames of one parity the lane mask of an
-// aligned tile is one 64-bit word; a tile that starts s rows into a block is a funnel of two neighbouring
-// words (five scalar instructions), and the operand register is one v_cndmask_b32 (mask ? 1.0 : 0.0).  The
-// masks arrive by scalar loads, so the vector unit issues one instruction per MFMA and there is no LDS.
+// aligned tile is one 64-bit word, and a tile that starts s rows into a block takes its lanes i < 16 - s from
+// word b shifted down by s and the others from word b + 1 shifted up by 16 - s.  The words arrive by scalar
+// loads (the blocks a wave needs for a step are contiguous), two scalar shifts and three v_cndmask_b32 (mask ?
+// 1.0 : 0.0 twice, then the lane select) make the operand register; there is no LDS.  The scalar unit issues one
+// instruction per SIMD every four cycles, eight per matrix instruction: the first version of this kernel,
+// which merged the two words with and/andn2/or on the scalar side (8.1 scalar instructions per MFMA with its
+// address arithmetic), was bound by exactly that (0.53 ms on config 2).
 //
 // Roofline: matrix-core bound.  P/32 tiles x (L+1) Dp/4 MFMAs x ceil(M/8) groups, 32 cycles each.
 #include "tsr_internal.h"
@@ -30,7 +34,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMaxNT = 3;       // tiles (of 32 frames) a wave carries through one pass over the taps
-constexpr int kWavesPerCU = 12; // three per SIMD
+constexpr int kWavesPerCU = 20; // five per SIMD (measured: 12: 483 us, 20: 451, 28: 445 on config 2)
 
 // One wave per 64 frames (two blocks).  Lane l = 16 c + i reads row 32 (2 w + (c >> 1)) + 2 i + (c & 1), so that the
 // ballot of feature k is four 16-bit fields (block half, parity) and lane c < 4 assembles word c from the four
@@ -48,7 +52,8 @@ __global__ __launch_bounds__(256) void exact_planes_kernel(const uint8_t *__rest
     const int sh = 16 * (lane & 3);
     const int q = lane & 1;
     const int64_t b = 2 * w + ((lane & 3) >> 1);
-    unsigned long long *dst = planes + ((int64_t)q * nb + b) * NK;
+    const int NK4 = NK >> 2;
+    unsigned long long *dst = planes + ((int64_t)q * NK4 * nb + b) * 4;  // + n4 * nb * 4 + u
     const bool wr = lane < 4 && b < nb;
     for (int n4 = 0; n4 < (NK >> 2); ++n4) {
         uint4 x = make_uint4(0, 0, 0, 0);
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(256) void exact_planes_kernel(const uint8_t *__rest
                 const unsigned long long bal = __ballot((dw[u] >> (8 * k)) & 0xffu);
                 res |= ((bal >> sh) & 0xffffull) << (16 * k);
             }
-            if (wr) dst[4 * n4 + u] = res;
+            if (wr) dst[(int64_t)n4 * nb * 4 + u] = res;
         }
     }
 }
@@ -85,28 +90,69 @@ __device__ __forceinline__ void exact_run(const unsigned long long *__restrict__
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    // One step = four K-steps of every tile: a float4 of B fragments and four words of each of the NT + 1 blocks.
+    // Two operand sets alternate: the loads of step it + 1 are issued in front of the matrix work of step it
+    // (the scalar and vector loads have a whole step, 4 NT matrix instructions, to arrive).
+    struct Step {
+        unsigned long long Q[NT + 1][4];
+        f32x4 bf;
+    };
     const f32x4 *wp = wg + lane;
-    for (int tp = 0; tp < Lg1; ++tp) {
-        const int s = (tp >> 1) & 15;
-        const unsigned long long lo = 0x0001000100010001ull * (unsigned long long)(0xffffu >> s);
-        const unsigned long long *st = planes + ((int64_t)(tp & 1) * nb + T0 + (tp >> 5)) * NK;
-        for (int n4 = 0; n4 < NK4; ++n4) {
-            const f32x4 bf = *wp;
-            wp += 64;
-            unsigned long long Q[NT + 1][4];
+    const int64_t step_words = nb * 4;  // from (q, n4) to (q, n4 + 1)
+    int ltp = 0, ln4 = 0;               // load cursor
+    const unsigned long long *lst = planes + T0 * 4;
+    auto load = [&](Step &o) {
+        o.bf = *wp;
+        wp += 64;
 #pragma unroll
-            for (int j = 0; j <= NT; ++j)
+        for (int j = 0; j <= NT; ++j)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) Q[j][u] = st[(int64_t)j * NK + 4 * n4 + u];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const unsigned long long mask = ((Q[t][u] >> s) & lo) | ((Q[t + 1][u] << (16 - s)) & ~lo);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(mask_to_operand(mask), bf[u], acc[t], 0, 0, 0);
-                }
+            for (int u = 0; u < 4; ++u) o.Q[j][u] = lst[4 * j + u];
+        lst += step_words;
+        if (++ln4 == NK4) {  // next tap row (a real branch, taken once in NK4 steps: the asm keeps it from being if-converted)
+            ln4 = 0;
+            ++ltp;
+            lst = planes + ((int64_t)(ltp & 1) * NK4 * nb + T0 + (ltp >> 5)) * 4;
         }
+    };
+    int ctp = 0, cn4 = 0;  // compute cursor
+    int sdn = 0, sup = 16;  // shifts of the current tap row: s = (tau' >> 1) & 15 and 16 - s
+    unsigned long long lo = 0xffffffffffffffffull;  // lanes i < 16 - s of every 16-lane field take the lower block's word
+    auto compute = [&](const Step &o) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#ifdef TSR_EXACT_VSEL
+                const float xa = mask_to_operand(o.Q[t][u] >> sdn);
+                const float xb = mask_to_operand(o.Q[t + 1][u] << sup);
+                const float x = __builtin_amdgcn_inverse_ballot_w64(lo) ? xa : xb;
+#elif defined(TSR_EXACT_NOFUNNEL)  // (timing experiment only: wrong sums)
+                const float x = mask_to_operand(o.Q[t][u]);
+#else
+                const float x = mask_to_operand(((o.Q[t][u] >> sdn) & lo) | ((o.Q[t + 1][u] << sup) & ~lo));
+#endif
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, o.bf[u], acc[t], 0, 0, 0);
+            }
+        if (++cn4 == NK4) {
+            cn4 = 0;
+            ++ctp;
+            sdn = (ctp >> 1) & 15;
+            sup = 16 - sdn;
+            lo = 0x0001000100010001ull * (unsigned long long)(0xffffu >> sdn);
+        }
+    };
+    const int total = Lg1 * NK4;
+    Step A, B;
+    load(A);
+    int it = 0;
+    for (; it + 2 <= total; it += 2) {
+        load(B);
+        compute(A);
+        load(A);  // (the step behind the last one is read and dropped: the planes and the fragments are padded for it)
+        compute(B);
     }
+    if (it < total) compute(A);
     // lane l holds rows i = 4 (l / 16) + r of column j = l % 16: template j & 7 at frame 32 T + 2 i + (j >> 3)
     const int j = lane & 15;
     const int m = j & 7;
@@ -184,7 +230,9 @@ int tsr_launch_exact_bank_mfma(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *c
     TSR_TRY(ensure_planes(ctx, cp, bank->Lmax));
     const int64_t nTiles = (cp->P + 31) / 32;
     const int64_t U = nTiles * bank->n_groups;
-    const int64_t slots = (int64_t)kWavesPerCU * ctx->cus;
+    int wpc = kWavesPerCU;
+    if (const char *e = getenv("TSR_EXACT_WPC")) wpc = std::max(1, atoi(e));  // (experiments)
+    const int64_t slots = (int64_t)wpc * ctx->cus;
     // as many waves as the chip holds at three per SIMD, but none with less than one tile
     const int64_t nW = std::max<int64_t>(1, std::min<int64_t>(slots, U));
     const unsigned grid = (unsigned)((nW + 3) / 4);

@@ -250,7 +250,7 @@ static int bank_build_exact(tsr_ctx *ctx, tsr_bank *b)
             gm_off[g] = total4;
             total4 += (int64_t)(b->gx_L[g] + 1) * NK4 * 64;
         }
-        Wm.assign((size_t)(total4 + 64) * 4, 0.0f);  // (+ one fragment: the kernel's last load may be a step ahead)
+        Wm.assign((size_t)(total4 + 128) * 4, 0.0f);  // (+ two fragments: the kernel loads up to two steps ahead)
         std::vector<int64_t> wstart(M + 1, 0);
         for (int m = 0; m < M; ++m) wstart[m + 1] = wstart[m] + (int64_t)b->L[m] * D;
         for (int g = 0; g < b->n_groups; ++g)

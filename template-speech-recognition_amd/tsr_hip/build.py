@@ -11,6 +11,9 @@ LIB = os.path.join(PKG, "lib", "libtsr_hip.so")
 SOURCES = ["tsr_api.hip", "detect_exact.hip", "detect_exact_mfma.hip", "detect_mfma.hip", "detect_mfma_i0.hip", "detect_mfma_i1.hip", "detect_mfma_i2.hip", "detect_mfma_i3.hip", "detect_mfma_i4.hip", "detect_mfma_i5.hip", "parts.hip", "parts_mfma.hip", "classify.hip", "edges.hip", "edges2.hip", "detect_mfma_bf16.hip", "detect_mfma_tap2_i0.hip", "detect_mfma_tap2_i1.hip", "detect_mfma_tap2_i2.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wextra", "-Wno-unused-parameter"]
+# per-source extras: matrix instructions with VGPR accumulators (with AGPR accumulators the register allocator
+# rotates the three accumulator tiles of detect_exact_mfma.hip through sixteen copies per loop iteration)
+EXTRA = {"detect_exact_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 HEADERS = [os.path.join(CSRC, "tsr_internal.h"), os.path.join(CSRC, "detect_mfma_kernel.inc"), os.path.join(CSRC, "detect_mfma_tap2.inc"),
            os.path.join(os.path.dirname(PKG), "include", "tsr.h")]
 
@@ -27,7 +30,7 @@ def build(force=False, verbose=False):
         s, o = os.path.join(CSRC, src), os.path.join(OBJ, src + ".o")
         objs.append(o)
         if force or _newer(o, [s] + HEADERS):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             procs.append((cmd, subprocess.Popen(cmd)))

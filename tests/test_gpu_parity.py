@@ -1277,3 +1277,52 @@ def test_tap_pair_kernel_parity(mods, oracle):
             assert rel_err(got[0], want[0]) <= 1e-6 and rel_err(got_all, want_all) <= 1e-6
         dc.score(bank, tsr_hip.TSR_EXACT)
         assert rel_err(got[0], dc.download()[0]) <= TOL
+
+
+def test_exact_on_matrix_cores_equals_vector_kernel_bit_for_bit(mods, oracle):
+    """TSR_EXACT runs on the matrix cores (csrc/detect_exact_mfma.hip: v_mfma_f32_16x16x4_f32 chains over bit planes of
+    the frames); TSR_EXACTK=valu keeps the one-lane-per-window kernel.  Same additions in the same order: every
+    score of every template identical, on ragged corpora, template counts off the group size of eight, filter
+    lengths from 1 to past two blocks of frames, feature counts off the 16-byte row grid, and against the oracle."""
+    import os
+    tsr_hip = mods[3]
+    from tsr_hip import synth
+    rng = np.random.default_rng(91)
+    T1 = rng.integers(0, 90, size=40)
+    cases = [synth.corpus(31, N=40, T=T1, F=5, E=3, M=3, L=[1, 7, 33]),
+             synth.corpus(32, N=6, T=[200, 3, 64, 65, 0, 31], F=45, E=8, M=8, L=32),
+             synth.corpus(33, N=9, T=120, F=13, E=2, M=20, L=[1 + (5 * m) % 70 for m in range(20)]),
+             synth.corpus(34, N=300, T=200, F=45, E=8, M=8, L=[20, 24, 28, 32, 36, 40, 44, 48])]
+    for c in cases:
+        P = int(c["offsets"][-1])
+        bank = tsr_hip.Bank(c["bank"])
+        dc = tsr_hip.Corpus(c["feats"].reshape(P, -1), c["offsets"])
+        dc.score(bank, tsr_hip.TSR_EXACT)
+        got = dc.download()
+        got_all = dc.score_all(bank, tsr_hip.TSR_EXACT)
+        os.environ["TSR_EXACTK"] = "valu"
+        try:
+            dc.score(bank, tsr_hip.TSR_EXACT)
+            want = dc.download()
+            want_all = dc.score_all(bank, tsr_hip.TSR_EXACT)
+        finally:
+            del os.environ["TSR_EXACTK"]
+        assert np.array_equal(got_all, want_all)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        if P <= 8000:
+            so, ao = oracle.score_corpus(c["feats"], c["offsets"], c["bank"])
+            assert np.array_equal(got[0], so) and np.array_equal(got[1], ao)
+
+
+def test_exact_bank_with_subnormal_weights_stays_on_the_vector_kernel(mods, oracle):
+    """The matrix-core form is built only for banks whose partial sums can never be subnormal (every non-zero
+    |w| >= 2^-100); a bank with tiny weights is served by the vector kernel and still matches the oracle's bits."""
+    tsr_hip = mods[3]
+    from tsr_hip import synth
+    c = synth.corpus(35, N=4, T=[50, 20, 33, 9], F=6, E=4, M=2, L=[5, 9])
+    tiny = [(np.asarray(w, np.float32) * np.float32(1e-38), 0.0) for w, _ in c["bank"]]
+    so, ao = oracle.score_corpus(c["feats"], c["offsets"], tiny)
+    bank = tsr_hip.Bank(tiny)
+    s, a = bank.score(c["feats"], c["offsets"], flags=tsr_hip.TSR_EXACT)
+    assert np.array_equal(s, so) and np.array_equal(a, ao)
+    assert np.any(s != 0)
