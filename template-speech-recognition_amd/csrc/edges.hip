@@ -10,7 +10,8 @@
 //   1. evaluates the stencil from the f64 spectrogram: the first difference along the orientation,
 //      kept where it is >= both neighbouring differences and of the orientation's sign;
 //   2. finds the reference's threshold -- element int(q n) of the sorted positive values -- by an
-//      8-pass radix select on the f64 bit patterns (positive doubles order like their bits), no sort;
+//      radix select (8-bit digits, at most 8 passes, stops when one candidate is left) on the f64 bit patterns
+//      (positive doubles order like their bits), no sort;
 //   3. thresholds at max(tau, abst[e]) and ORs the binary block along the orientation
 //      (+-spread_length steps, zeros outside the BLOCK, like the reference's zero-padded Z);
 // and finally writes the block's frames in the resident corpus layout [frame][h*8 + e] as whole rows.
@@ -208,9 +209,17 @@ __global__ __launch_bounds__(512) void edge_block_wave_kernel(const EdgeArgs a)
     uint8_t *tile = esm;                                            // [W][Dp]
     uint8_t *bin = tile + (size_t)a.max_w * a.Dp + (size_t)e * hw;  // this wave's [H][W]
     int *hist = reinterpret_cast<int *>(tile + (size_t)a.max_w * a.Dp + 8 * hw) + e * 256;
-
+    // the block's spectrogram frames (one before, two behind: the stencil's reach) staged once with coalesced
+    // loads: the eight orientation waves read every value up to six times each
+    double *Sl = reinterpret_cast<double *>(tile + (size_t)a.max_w * a.Dp + 8 * hw + 8 * 256 * 4);
+    const int f_lo = max(c0 - 1, 0), f_hi = min(c0 + W + 2, T);
+    {
+        const double *src = a.S + (o + f_lo) * H;
+        for (int i = tid; i < (f_hi - f_lo) * H; i += 512) Sl[i] = src[i];
+    }
     for (int i = tid * 16; i < W * a.Dp; i += 512 * 16) *reinterpret_cast<uint4 *>(tile + i) = make_uint4(0, 0, 0, 0);
-    auto Sv = [&](int h, int t) { return a.S[(o + t) * H + h]; };
+    __syncthreads();
+    auto Sv = [&](int h, int t) { return Sl[(t - f_lo) * H + h]; };
     const int pair = e >> 1;
     const double sg = (e & 1) ? -1.0 : 1.0;
     // ---- 1. stencil into registers ------------------------------------------------------------------
@@ -265,7 +274,10 @@ __global__ __launch_bounds__(512) void edge_block_wave_kernel(const EdgeArgs a)
     if (n > 0) {
         unsigned long long prefix = 0;
         int kk = (int)(a.q * (double)n);
+        bool done = false;  // (wave-uniform)
+#pragma unroll
         for (int pass = 7; pass >= 0; --pass) {
+            if (done) continue;
             const int shift = 8 * pass;
 #pragma unroll
             for (int b = 0; b < 4; ++b) hist[4 * lane + b] = 0;
@@ -299,9 +311,24 @@ __global__ __launch_bounds__(512) void edge_block_wave_kernel(const EdgeArgs a)
             }
             const int src = __builtin_ctzll(__builtin_amdgcn_ballot_w64(mine));  // exactly one lane holds k
             const int digit = __shfl(4 * lane + b, src);
+            const int cnt = __shfl(b == 0 ? h0 : (b == 1 ? h1 : (b == 2 ? h2 : h3)), src);
             kk = __shfl(kk - cum, src);
             prefix |= (unsigned long long)digit << shift;
             __builtin_amdgcn_wave_barrier();  // everyone has read the histogram before it is cleared again
+            if (cnt == 1 && pass > 0) {
+                // one value left under this prefix: it is the k-th smallest, whatever its remaining digits are
+                // (random spectrogram differences separate after three or four digits; ties run all eight passes)
+                unsigned long long found = 0;
+#pragma unroll
+                for (int i = 0; i < EPL; ++i)
+                    if (v[i] > 0.0) {
+                        const unsigned long long key = (unsigned long long)__double_as_longlong(v[i]);
+                        if ((key >> shift) == (prefix >> shift)) found = key;
+                    }
+                const int owner = __builtin_ctzll(__builtin_amdgcn_ballot_w64(found != 0));
+                prefix = ((unsigned long long)(unsigned)__shfl((int)(found >> 32), owner) << 32) | (unsigned)__shfl((int)found, owner);
+                done = true;
+            }
         }
         const double tau = __longlong_as_double((long long)prefix);
         thr = tau > a.abst[e] ? tau : a.abst[e];
@@ -370,7 +397,7 @@ int tsr_launch_edge_blocks(tsr_ctx *ctx, const double *d_S, const uint8_t *d_mas
     const size_t hw = (size_t)H * block_length;
     {  // one wave per orientation while the block fits the lanes' registers
         const size_t hw16 = (hw + 15) & ~(size_t)15;
-        const size_t lds_w = (size_t)block_length * Dp + 8 * hw16 + 8 * 256 * 4;
+        const size_t lds_w = (size_t)block_length * Dp + 8 * hw16 + 8 * 256 * 4 + (size_t)(block_length + 3) * H * 8;
         if (hw <= 64 * 32 && lds_w <= 64 * 1024) {
             if (hw <= 64 * 8) return launch_edge_wave<8>(ctx, a, n_items, lds_w);
             if (hw <= 64 * 16) return launch_edge_wave<16>(ctx, a, n_items, lds_w);
