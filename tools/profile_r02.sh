@@ -40,6 +40,23 @@ c45x)  # the same bank with the round-robin block mapping (column groups of a se
   timeout -k 10 300 python3 tools/time_config45.py fast 4 5 > gpurun_out/r02_config45_roundrobin_timing.txt 2>&1 && cat gpurun_out/r02_config45_roundrobin_timing.txt && \
   pmc c45x_fetch FETCH_SIZE tools/time_config45.py fast 4 1 || exit 1
   unset TSR_XCD_MAP ;;
+misc)  # the rows either side of the path: config 3, classification, edges, mixture, the whole pipeline
+  bash tools/kstat3.sh 1000 > gpurun_out/r02_config3.log 2>&1 && cp gpurun_out/ks3/ks3_kernel_stats.csv gpurun_out/r02_config3_kernel_stats.csv && \
+  bash tools/kstat_cls.sh > gpurun_out/r02_classify.log 2>&1 && cp gpurun_out/kcls/kcls_kernel_stats.csv gpurun_out/r02_classify_kernel_stats.csv && \
+  grep -v "^E2026\|^W2026" gpurun_out/kcls.log | tail -6 > gpurun_out/r02_classify_timing.txt && \
+  timeout -k 10 300 python3 tools/time_mixture.py > gpurun_out/r02_mixture_timing.txt 2>&1 && \
+  timeout -k 10 300 python3 tools/time_pipeline.py > gpurun_out/r02_pipeline_timing.txt 2>&1 && \
+  timeout -k 10 300 python3 tools/time_edges.py 1000 > gpurun_out/r02_edges_timing.txt 2>&1 && \
+  timeout -k 10 300 python3 tools/time_dropins.py > gpurun_out/r02_dropins_timing.txt 2>&1 || exit 1
+  tail -3 gpurun_out/r02_config3.log; cat gpurun_out/r02_classify_timing.txt gpurun_out/r02_mixture_timing.txt gpurun_out/r02_pipeline_timing.txt gpurun_out/r02_edges_timing.txt gpurun_out/r02_dropins_timing.txt ;;
+exactk)  # TSR_EXACT: the matrix-core kernel against the vector kernel, configs 2, 2b and 4
+  { timeout -k 10 200 python3 tools/ab_kernel.py TSR_EXACTK valu,mfma 4 5 2 0 | tail -3 && \
+    timeout -k 10 200 python3 tools/ab_kernel.py TSR_EXACTK valu,mfma 4 5 2b 0 | tail -3 && \
+    timeout -k 10 200 python3 tools/ab_kernel.py TSR_EXACTK valu,mfma 2 3 4 0 | tail -3 && \
+    timeout -k 10 200 python3 tools/ab_kernel.py TSR_FASTK old,tap2 8 7 2 | tail -3 && \
+    timeout -k 10 200 python3 tools/ab_kernel.py TSR_FASTK old,tap2 4 5 4 | tail -3; } > gpurun_out/r02_kernel_ab.txt 2>&1 || exit 1
+  cat gpurun_out/r02_kernel_ab.txt
+  pmc exact_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU" bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-modes --mode exact || exit 1 ;;
 esac
 done
 echo "profile_r02 done: $PARTS"

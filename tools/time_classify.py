@@ -40,7 +40,13 @@ for flags, name in ((tsr_hip.TSR_EXACT, "exact"), (tsr_hip.TSR_FAST, "fast")):
 t0 = time.perf_counter()
 per = [gtrd._isolated_virtual_windows(T, f, L, frame0=int(offs[n])) for n, f in enumerate(flts)]
 cat = [np.concatenate([p[i] for p in per]) for i in range(5)]
+t_loop = time.perf_counter() - t0
+t0 = time.perf_counter()
+batch = gtrd._isolated_virtual_windows_batch([T] * N, flts, L, [int(o) for o in offs[:-1]])
 t_glue = time.perf_counter() - t0
+assert all(np.array_equal(a, b) for a, b in zip(cat, batch[:5]))
+print("isolated-window geometry on the host: %.1f ms as one pass of array operations (what get_classify_scores_E uses), "
+      "%.1f ms as the per-utterance loop" % (t_glue * 1e3, t_loop * 1e3))
 best = 1e9
 for _ in range(4):
     ctx.sync(); t0 = time.perf_counter()
