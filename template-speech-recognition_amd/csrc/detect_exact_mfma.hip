@@ -80,36 +80,43 @@ __device__ __forceinline__ float mask_to_operand(unsigned long long mask)
     return __builtin_amdgcn_inverse_ballot_w64(mask) ? 1.0f : 0.0f;
 }
 
-// NT tiles T0 .. T0+NT-1 of one template group through all taps; raw scores of the group's templates out.
-template <int NT>
+// NT tiles T0 .. T0+NT-1 of NG template groups (a pair shares the operand masks: half the scalar work per matrix
+// instruction) through all taps; raw scores of the groups' templates out.
+template <int NT, int NG>
 __device__ __forceinline__ void exact_run(const unsigned long long *__restrict__ planes, int64_t nb, int NK,
-                                          const f32x4 *__restrict__ wg, int Lg1, int64_t T0, int lane, float *__restrict__ raw_g,
-                                          int64_t P, int Mg)
+                                          const f32x4 *__restrict__ wg0, const f32x4 *__restrict__ wg1, int Lg1, int64_t T0, int lane,
+                                          float *__restrict__ raw_g, int64_t P, int Mg)
 {
     const int NK4 = NK >> 2;
-    f32x4 acc[NT];
+    f32x4 acc[NG][NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    // One step = four K-steps of every tile: a float4 of B fragments and four words of each of the NT + 1 blocks.
-    // Two operand sets alternate: the loads of step it + 1 are issued in front of the matrix work of step it
-    // (the scalar and vector loads have a whole step, 4 NT matrix instructions, to arrive).
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[g][t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    // One step = four K-steps of every tile: a float4 of B fragments per group and four words of each of the NT + 1
+    // blocks.  Two operand sets alternate: the loads of step it + 1 are issued in front of the matrix work of step it
+    // (the scalar and vector loads have a whole step, 4 NT NG matrix instructions, to arrive).
     struct Step {
         unsigned long long Q[NT + 1][4];
-        f32x4 bf;
+        f32x4 bf[NG];
     };
-    const f32x4 *wp = wg + lane;
+    const f32x4 *wp0 = wg0 + lane, *wp1 = wg1 + lane;
     const int64_t step_words = nb * 4;  // from (q, n4) to (q, n4 + 1)
     int ltp = 0, ln4 = 0;               // load cursor
     const unsigned long long *lst = planes + T0 * 4;
     auto load = [&](Step &o) {
-        o.bf = *wp;
-        wp += 64;
+        o.bf[0] = *wp0;
+        wp0 += 64;
+        if (NG == 2) {
+            o.bf[NG - 1] = *wp1;
+            wp1 += 64;
+        }
 #pragma unroll
         for (int j = 0; j <= NT; ++j)
 #pragma unroll
             for (int u = 0; u < 4; ++u) o.Q[j][u] = lst[4 * j + u];
         lst += step_words;
-        if (++ln4 == NK4) {  // next tap row (a real branch, taken once in NK4 steps: the asm keeps it from being if-converted)
+        if (++ln4 == NK4) {  // next tap row
             ln4 = 0;
             ++ltp;
             lst = planes + ((int64_t)(ltp & 1) * NK4 * nb + T0 + (ltp >> 5)) * 4;
@@ -123,16 +130,9 @@ __device__ __forceinline__ void exact_run(const unsigned long long *__restrict__
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-#ifdef TSR_EXACT_VSEL
-                const float xa = mask_to_operand(o.Q[t][u] >> sdn);
-                const float xb = mask_to_operand(o.Q[t + 1][u] << sup);
-                const float x = __builtin_amdgcn_inverse_ballot_w64(lo) ? xa : xb;
-#elif defined(TSR_EXACT_NOFUNNEL)  // (timing experiment only: wrong sums)
-                const float x = mask_to_operand(o.Q[t][u]);
-#else
                 const float x = mask_to_operand(((o.Q[t][u] >> sdn) & lo) | ((o.Q[t + 1][u] << sup) & ~lo));
-#endif
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, o.bf[u], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, o.bf[g][u], acc[g][t], 0, 0, 0);
             }
         if (++cn4 == NK4) {
             cn4 = 0;
@@ -156,24 +156,27 @@ __device__ __forceinline__ void exact_run(const unsigned long long *__restrict__
     // lane l holds rows i = 4 (l / 16) + r of column j = l % 16: template j & 7 at frame 32 T + 2 i + (j >> 3)
     const int j = lane & 15;
     const int m = j & 7;
-    if (m < Mg) {
-        float *dst = raw_g + (int64_t)m * P;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+    for (int g = 0; g < NG; ++g)
+        if (g * TSR_MG + m < Mg) {
+            float *dst = raw_g + (int64_t)(g * TSR_MG + m) * P;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t p = 32 * (T0 + t) + 2 * (4 * (lane >> 4) + r) + (j >> 3);
-                if (p < P) dst[p] = acc[t][r];
-            }
-    }
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t p = 32 * (T0 + t) + 2 * (4 * (lane >> 4) + r) + (j >> 3);
+                    if (p < P) dst[p] = acc[g][t][r];
+                }
+        }
 }
 
-// Units u = g * nTiles + T are dealt to the waves in contiguous, equally long ranges; a wave walks its range in
-// runs of up to kMaxNT tiles of one group.
+// Units u = pair * nTiles + T (pair = two consecutive template groups, the last one may be single) are dealt to the
+// waves in contiguous, equally long ranges; a wave walks its range in runs of up to kMaxNT tiles of one pair.
+template <bool PAIRS>  // (two instantiations: the pair form needs 100 registers, the single-group form 68 = one more wave per SIMD)
 __global__ __launch_bounds__(256) void exact_mfma_kernel(const unsigned long long *__restrict__ planes, int64_t nb, int NK,
                                                          const f32x4 *__restrict__ wmf, const int64_t *__restrict__ gm_off,
-                                                         const int32_t *__restrict__ gx_L, int64_t nTiles, int64_t U, int64_t nW,
-                                                         int M, int64_t P, float *__restrict__ raw)
+                                                         const int32_t *__restrict__ gm_rows, int n_groups, int64_t nTiles, int64_t U,
+                                                         int64_t nW, int M, int64_t P, float *__restrict__ raw)
 {
     const int lane = threadIdx.x & 63;
     const int64_t w = __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6));
@@ -181,18 +184,29 @@ __global__ __launch_bounds__(256) void exact_mfma_kernel(const unsigned long lon
     int64_t u = (U * w) / nW;
     const int64_t hi = (U * (w + 1)) / nW;
     while (u < hi) {
-        const int64_t g = u / nTiles, T0 = u - g * nTiles;
+        const int64_t pair = u / nTiles, T0 = u - pair * nTiles;
+        const int g = PAIRS ? 2 * (int)pair : (int)pair;
         const int nt = (int)min((int64_t)kMaxNT, min(hi - u, nTiles - T0));
-        const f32x4 *wg = wmf + gm_off[g];
-        const int Lg1 = gx_L[g] + 1;
-        float *raw_g = raw + g * TSR_MG * P;
-        const int Mg = min(TSR_MG, M - (int)g * TSR_MG);
-        if (nt == 3)
-            exact_run<3>(planes, nb, NK, wg, Lg1, T0, lane, raw_g, P, Mg);
-        else if (nt == 2)
-            exact_run<2>(planes, nb, NK, wg, Lg1, T0, lane, raw_g, P, Mg);
-        else
-            exact_run<1>(planes, nb, NK, wg, Lg1, T0, lane, raw_g, P, Mg);
+        const bool two = PAIRS && g + 1 < n_groups;
+        const f32x4 *wg0 = wmf + gm_off[g], *wg1 = wmf + gm_off[two ? g + 1 : g];
+        const int rows = gm_rows[g];  // (both groups of a pair are laid out with the same number of tap rows)
+        float *raw_g = raw + (int64_t)g * TSR_MG * P;
+        const int Mg = M - g * TSR_MG;  // templates from this pair's first one on
+        if (PAIRS && two) {
+            if (nt == 3)
+                exact_run<3, 2>(planes, nb, NK, wg0, wg1, rows, T0, lane, raw_g, P, Mg);
+            else if (nt == 2)
+                exact_run<2, 2>(planes, nb, NK, wg0, wg1, rows, T0, lane, raw_g, P, Mg);
+            else
+                exact_run<1, 2>(planes, nb, NK, wg0, wg1, rows, T0, lane, raw_g, P, Mg);
+        } else {
+            if (nt == 3)
+                exact_run<3, 1>(planes, nb, NK, wg0, wg1, rows, T0, lane, raw_g, P, Mg);
+            else if (nt == 2)
+                exact_run<2, 1>(planes, nb, NK, wg0, wg1, rows, T0, lane, raw_g, P, Mg);
+            else
+                exact_run<1, 1>(planes, nb, NK, wg0, wg1, rows, T0, lane, raw_g, P, Mg);
+        }
         u += nt;
     }
 }
@@ -229,16 +243,22 @@ int tsr_launch_exact_bank_mfma(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *c
     if (cp->P == 0) return TSR_OK;
     TSR_TRY(ensure_planes(ctx, cp, bank->Lmax));
     const int64_t nTiles = (cp->P + 31) / 32;
-    const int64_t U = nTiles * bank->n_groups;
-    int wpc = kWavesPerCU;
+    const bool pairs = bank->n_groups > 1;
+    const int64_t U = nTiles * (pairs ? (bank->n_groups + 1) / 2 : 1);
+    int wpc = pairs ? 16 : kWavesPerCU;  // (the pair form fits four waves per SIMD)
     if (const char *e = getenv("TSR_EXACT_WPC")) wpc = std::max(1, atoi(e));  // (experiments)
     const int64_t slots = (int64_t)wpc * ctx->cus;
-    // as many waves as the chip holds at three per SIMD, but none with less than one tile
+    // as many waves as the chip is to hold, but none with less than one tile
     const int64_t nW = std::max<int64_t>(1, std::min<int64_t>(slots, U));
     const unsigned grid = (unsigned)((nW + 3) / 4);
-    hipLaunchKernelGGL(exact_mfma_kernel, dim3(grid), dim3(256), 0, ctx->stream, reinterpret_cast<const unsigned long long *>(cp->d_planes),
-                       cp->planes_nb, cp->Dp / 4, reinterpret_cast<const f32x4 *>(bank->d_Wm), bank->d_gm_off, bank->d_gx_L, nTiles, U, nW,
-                       bank->M, cp->P, d_raw);
+    if (pairs)
+        hipLaunchKernelGGL(exact_mfma_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream, reinterpret_cast<const unsigned long long *>(cp->d_planes),
+                           cp->planes_nb, cp->Dp / 4, reinterpret_cast<const f32x4 *>(bank->d_Wm), bank->d_gm_off, bank->d_gm_rows,
+                           bank->n_groups, nTiles, U, nW, bank->M, cp->P, d_raw);
+    else
+        hipLaunchKernelGGL(exact_mfma_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, reinterpret_cast<const unsigned long long *>(cp->d_planes),
+                           cp->planes_nb, cp->Dp / 4, reinterpret_cast<const f32x4 *>(bank->d_Wm), bank->d_gm_off, bank->d_gm_rows,
+                           bank->n_groups, nTiles, U, nW, bank->M, cp->P, d_raw);
     TSR_HIP(hipGetLastError());
     return TSR_OK;
 }

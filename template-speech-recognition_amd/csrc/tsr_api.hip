@@ -243,18 +243,22 @@ static int bank_build_exact(tsr_ctx *ctx, tsr_bank *b)
     for (float w : b->W_cat) mfma_ok = mfma_ok && std::isfinite(w) && (w == 0.0f || std::fabs(w) >= 0x1p-100f);
     const int Dp = (int)((D + 15) / 16 * 16), NK4 = Dp / 16;
     std::vector<int64_t> gm_off(b->n_groups, 0);
+    std::vector<int32_t> gm_rows(b->n_groups, 0);
     std::vector<float> Wm;
     if (mfma_ok) {
         int64_t total4 = 0;
         for (int g = 0; g < b->n_groups; ++g) {
+            // the kernel takes two groups at a time through the taps: both get the pair's number of tap rows
+            const int mate = (g ^ 1) < b->n_groups ? (g ^ 1) : g;
+            gm_rows[g] = std::max(b->gx_L[g], b->gx_L[mate]) + 1;
             gm_off[g] = total4;
-            total4 += (int64_t)(b->gx_L[g] + 1) * NK4 * 64;
+            total4 += (int64_t)gm_rows[g] * NK4 * 64;
         }
         Wm.assign((size_t)(total4 + 128) * 4, 0.0f);  // (+ two fragments: the kernel loads up to two steps ahead)
         std::vector<int64_t> wstart(M + 1, 0);
         for (int m = 0; m < M; ++m) wstart[m + 1] = wstart[m] + (int64_t)b->L[m] * D;
         for (int g = 0; g < b->n_groups; ++g)
-            for (int tp = 0; tp <= b->gx_L[g]; ++tp)
+            for (int tp = 0; tp < gm_rows[g]; ++tp)
                 for (int n4 = 0; n4 < NK4; ++n4)
                     for (int lane = 0; lane < 64; ++lane) {
                         const int k = lane >> 4, j = lane & 15, m = g * TSR_MG + (j & 7), tau = tp - (j >> 3);
@@ -270,6 +274,7 @@ static int bank_build_exact(tsr_ctx *ctx, tsr_bank *b)
     // (re)build leaves the old, self-consistent bank behind
     float *n_Wx = nullptr, *n_cf = nullptr, *n_Wm = nullptr;
     int64_t *n_off = nullptr, *n_gm = nullptr;
+    int32_t *n_gr = nullptr;
     int32_t *n_gL = nullptr, *n_L = nullptr;
     int s = dev_upload(ctx, &n_Wx, Wx.data(), Wx.size());
     if (s == TSR_OK) s = dev_upload(ctx, &n_off, b->gx_off.data(), b->gx_off.size());
@@ -278,6 +283,7 @@ static int bank_build_exact(tsr_ctx *ctx, tsr_bank *b)
     if (s == TSR_OK) s = dev_upload(ctx, &n_cf, cf.data(), cf.size());
     if (s == TSR_OK && mfma_ok) s = dev_upload(ctx, &n_Wm, Wm.data(), Wm.size());
     if (s == TSR_OK && mfma_ok) s = dev_upload(ctx, &n_gm, gm_off.data(), gm_off.size());
+    if (s == TSR_OK && mfma_ok) s = dev_upload(ctx, &n_gr, gm_rows.data(), gm_rows.size());
     if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {  // host staging vectors die here
         tsr_set_error("bank upload failed");
         s = TSR_ERR_HIP;
@@ -290,12 +296,15 @@ static int bank_build_exact(tsr_ctx *ctx, tsr_bank *b)
         dev_free(n_cf);
         dev_free(n_Wm);
         dev_free(n_gm);
+        dev_free(n_gr);
         return s;
     }
     dev_free(b->d_Wm);
     dev_free(b->d_gm_off);
+    dev_free(b->d_gm_rows);
     b->d_Wm = n_Wm;
     b->d_gm_off = n_gm;
+    b->d_gm_rows = n_gr;
     b->wm_Dp = Dp;
     dev_free(b->d_Wx);
     dev_free(b->d_gx_off);
@@ -367,6 +376,7 @@ TSR_API int tsr_bank_destroy(tsr_bank *b)
     dev_free(b->d_Wx);
     dev_free(b->d_Wm);
     dev_free(b->d_gm_off);
+    dev_free(b->d_gm_rows);
     dev_free(b->d_gx_off);
     dev_free(b->d_gx_L);
     dev_free(b->d_L);

@@ -103,6 +103,7 @@ struct tsr_bank {
     // absent (null) when a weight is not finite or small enough for subnormal partial sums
     float *d_Wm = nullptr;
     int64_t *d_gm_off = nullptr;     // float4 offset of group g in d_Wm
+    int32_t *d_gm_rows = nullptr;    // tap rows of group g in d_Wm: max(L_g) + 1 over the group's pair (2p, 2p + 1)
     int wm_Dp = 0;                   // resident row stride the fragments were laid out for
     // device, fast path (built lazily by detect_mfma.hip): [0] two int8 limbs, [1] three, [2] bf16, [3] bf16 hi + lo,
     // [4] two int8 limbs with two taps folded into K (tap2_bank_kernel, narrow feature rows)

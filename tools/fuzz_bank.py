@@ -10,20 +10,50 @@ import tsr_hip, oracle
 from tsr_hip import synth
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-bad = 0
+LARGE = "--large" in sys.argv   # corpora of 20 000 .. 120 000 frames: the kernels' steady-state tiles, segments cut
+bad = 0                         # inside utterances, several column groups, the tap-pair variant as a third approximate path
 for case in range(n_cases):
-    N = int(rng.integers(1, 7))
-    M = int(rng.choice([1, 2, 3, 8, 9, 17, 33]))
-    F, E = int(rng.integers(1, 40)), int(rng.choice([1, 3, 8, 16, 50]))
-    Ls = [int(x) for x in rng.integers(1, 70, size=M)]
-    Ts = [int(x) for x in rng.integers(0, 400, size=N)]
+    if LARGE:
+        N = int(rng.integers(30, 500))
+        M = int(rng.choice([1, 3, 8, 9, 20]))
+        F, E = int(rng.choice([5, 23, 45, 46])), int(rng.choice([3, 8]))
+        Ls = [int(x) for x in rng.integers(1, 60, size=M)]
+        Ts = [int(x) for x in rng.integers(0, 480, size=N)]
+        if rng.random() < 0.3:
+            Ts[int(rng.integers(N))] = int(rng.integers(3000, 40000))   # one very long utterance
+    else:
+        N = int(rng.integers(1, 7))
+        M = int(rng.choice([1, 2, 3, 8, 9, 17, 33]))
+        F, E = int(rng.integers(1, 40)), int(rng.choice([1, 3, 8, 16, 50]))
+        Ls = [int(x) for x in rng.integers(1, 70, size=M)]
+        Ts = [int(x) for x in rng.integers(0, 400, size=N)]
     c = synth.corpus(int(rng.integers(1 << 30)), N=N, T=Ts, F=F, E=E, M=M, L=Ls)
     bank = tsr_hip.Bank(c["bank"])
     se, ae = bank.score(c["feats"], c["offsets"], flags=tsr_hip.TSR_EXACT)
-    so, ao = oracle.score_corpus(c["feats"], c["offsets"], c["bank"])
-    ok = np.array_equal(se, so) and np.array_equal(ae, ao)
-    msg = "" if ok else " EXACT!=ORACLE"
-    for flags in (1, 3):
+    if LARGE:   # the oracle on a few utterances; the vector kernel (TSR_EXACTK=valu) on all of them
+        offs = c["offsets"]
+        pick = rng.choice(N, size=min(N, 5), replace=False)
+        ok = True
+        for n in pick:
+            sl = slice(int(offs[n]), int(offs[n + 1]))
+            if sl.stop - sl.start > 2500 or sl.stop == sl.start:
+                continue
+            so, ao = oracle.score_bank(c["feats"][sl], c["bank"])
+            ok = ok and np.array_equal(se[sl], so) and np.array_equal(ae[sl], ao)
+        os.environ["TSR_EXACTK"] = "valu"
+        sv, av = bank.score(c["feats"], c["offsets"], flags=tsr_hip.TSR_EXACT)
+        del os.environ["TSR_EXACTK"]
+        msg = ("" if ok else " EXACT!=ORACLE") + ("" if np.array_equal(se, sv) and np.array_equal(ae, av) else " EXACT(mfma)!=EXACT(valu)")
+    else:
+        so, ao = oracle.score_corpus(c["feats"], c["offsets"], c["bank"])
+        ok = np.array_equal(se, so) and np.array_equal(ae, ao)
+        msg = "" if ok else " EXACT!=ORACLE"
+    for flags in ((1, 3, -1) if LARGE else (1, 3)):
+        if flags == -1:   # the tap-pair kernel (falls back to the default kernel where its geometry does not fit)
+            os.environ["TSR_FASTK"] = "tap2"
+            flags = 1
+        else:
+            os.environ.pop("TSR_FASTK", None)
         sf, af = bank.score(c["feats"], c["offsets"], flags=flags)
         err = float(np.max(np.abs(sf - se) / np.maximum(np.abs(se), 1.0))) if len(se) else 0.0
         if err > 1e-4:
@@ -44,4 +74,5 @@ for case in range(n_cases):
     if msg:
         bad += 1
         print("case %d N=%d M=%d D=%d Ls=%s Ts=%s:%s" % (case, N, M, F * E, Ls, Ts, msg))
-print("fuzz: %d cases, %d bad" % (n_cases, bad))
+os.environ.pop("TSR_FASTK", None)
+print("fuzz%s: %d cases, %d bad" % (" (large corpora)" if LARGE else "", n_cases, bad))
