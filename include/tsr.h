@@ -47,7 +47,9 @@ enum {
 /* Scoring precision/algorithm selector (`flags` of the bank scorers).
  *   TSR_EXACT: f32 accumulation in the reference's order tau -> f -> k
  *              (compute_likelihood_linear_filter.pyx:162-175); raw scores are
- *              bit-identical to the Cython path.
+ *              bit-identical to the Cython path.  Runs as v_mfma_f32_16x16x4_f32 chains (an
+ *              ascending-k fmaf chain per output) over bit planes of the corpus; banks with
+ *              a non-zero weight below 2^-100 take the one-lane-per-window vector kernel.
  *   TSR_FAST : MFMA path.  The bank is held as int8 limbs of a fixed-point encoding
  *              (per-template scale) and accumulated exactly in integers, so results
  *              are independent of summation order and bit-reproducible; the only
@@ -71,8 +73,9 @@ enum {
 enum { TSR_EXACT = 0, TSR_FAST = 1, TSR_W24 = 2, TSR_BF16 = 4 };
 /*   TSR_FAST | TSR_BF16 [| TSR_W24]: the bank as a bf16 MFMA GEMM (BASELINE configs[4]): weights rounded to bf16
  *              (relative error up to 2^-9 per weight: NOT within the 1e-4 bar) or, with TSR_W24, split into
- *              bf16 hi + lo (2^-17 per weight), f32 accumulation and f32 LDS atomics -- neither exact nor
- *              bit-reproducible.  Comparison variants only; D <= 384, otherwise the exact kernel serves the call. */
+ *              bf16 hi + lo (2^-17 per weight); f32 accumulation inside a 32-frame tile, tile sums rounded to
+ *              fixed point and added as integers (order-independent, hence bit-reproducible, but not exact).
+ *              Comparison variants only; D <= 384, otherwise the exact kernel serves the call. */
 
 typedef struct tsr_ctx tsr_ctx;       /* device + stream + scratch                 */
 typedef struct tsr_bank tsr_bank;     /* device-resident template bank             */
