@@ -216,7 +216,18 @@ def roofline_of(mode, per_launch_s, frames, traffic):
     # ridge, and each algorithmic MAC costs 2 (3) int8 limb-MACs, so the matrix cores bind
     tops = ALG_FLOPS / per_launch_s / 1e12
     limbs = 2 if mode == "fast" else 3
-    kpad = (math.ceil(D / 32) * 32) / D                       # K padded to whole 32-feature MFMA blocks
+    # which two-limb kernel tsr_corpus_score picks (tsr_api.hip): the tap-pair kernel when the bank is one column
+    # group (sum of ceil(L/2) <= 128) and the resident rows are an odd number (<= 23) of 16-byte slots
+    dp16 = math.ceil(D / 16)
+    forced = os.environ.get("TSR_FASTK", "")[:1]
+    tap_pair = mode == "fast" and (forced == "t" or (forced != "o" and CFG["M"] * math.ceil(CFG["L"] / 2) <= 128
+                                                     and dp16 % 2 == 1 and dp16 <= 23))
+    if tap_pair:   # K = two resident rows of 16 * dp16 bytes per tap pair; odd L would add half a tap per template
+        kpad = (16 * dp16) / D * (2 * math.ceil(CFG["L"] / 2)) / CFG["L"]
+        kpad_what = "K padding (%d/%d; tap-pair kernel)" % (16 * dp16, D)
+    else:          # K padded to whole 32-feature MFMA blocks
+        kpad = (math.ceil(D / 32) * 32) / D
+        kpad_what = "K padding (%d/%d)" % (math.ceil(D / 32) * 32, D)
     tail = CFG["T"] / (CFG["T"] - CFG["L"] + 1)               # tail frames run through the matrix cores too
     issued = tops * limbs * kpad * tail
     return {"bound": "mfma", "achieved": tops, "peak": MFMA_I8_PEAK_TOPS, "unit": "TFLOP/s",
@@ -224,8 +235,9 @@ def roofline_of(mode, per_launch_s, frames, traffic):
             "kernel_ms_per_launch": per_launch_s * 1e3, "alg_flops_per_launch": ALG_FLOPS,
             "issued": {"limb_macs_per_alg_mac": limbs, "k_pad": kpad, "tail_rows": tail,
                        "int8_tops": issued, "frac_of_peak": issued / MFMA_I8_PEAK_TOPS,
-                       "what": "int8 ops the kernel issues = algorithmic x limbs x K padding (384/360) x "
-                               "tail frames (200/169)"},
+                       "kernel": "tap2_bank_kernel" if tap_pair else ("fast_bank_kernel" if limbs == 2 else "alt_bank_kernel"),
+                       "what": "int8 ops the kernel issues = algorithmic x limbs x %s x tail frames (%d/%d)"
+                               % (kpad_what, CFG["T"], CFG["T"] - CFG["L"] + 1)},
             "peak_note": "dense int8 MFMA = 2x the ~2.5 PF bf16 dense peak (MI355X_MICROARCH.md)",
             "hbm": hbm}
 

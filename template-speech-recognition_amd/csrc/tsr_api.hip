@@ -529,11 +529,21 @@ static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp,
         if ((int64_t)bank->Lmax * bank->D > TSR_FAST_W24_ABOVE_TAPS) flags |= TSR_W24;
     }
     if (flags == TSR_FAST && !bank->tap2_unsupported) {
-        // TSR_FASTK=tap2 (read per launch: A/B measurements inside one process): two limbs on narrow feature rows
-        // with tap pairs folded into K (detect_mfma_tap2.inc).  Parity-green and level with the interleaved
-        // kernel on config 2 (34.6 vs 34.9 us), slower on wide banks, hence not the default.
+        // Two limbs on narrow feature rows: the tap-pair kernel (detect_mfma_tap2.inc: two taps folded into K, half the
+        // skew emission per matrix instruction) where the whole bank is one column group -- sum of ceil(L_m / 2) <= 128
+        // columns, rows of an odd number (<= 23) of 16-byte slots; config 2: 7 % faster than the interleaved kernel.
+        // With several column groups it is the slower one (0.95 vs 0.40 ms on config 4), so those banks stay on the
+        // interleaved kernel.  TSR_FASTK=tap2 / TSR_FASTK=old force one or the other (read per launch: A/B
+        // measurements inside one process).
         const char *e = getenv("TSR_FASTK");
-        if (e && e[0] == 't') {
+        bool want = e && e[0] == 't';
+        if (!e || (e[0] != 't' && e[0] != 'o')) {
+            int64_t cols = 0;
+            for (int32_t l : bank->L) cols += (l + 1) / 2;
+            const int nkb2 = cp->Dp / 16;
+            want = cols <= 128 && (nkb2 & 1) && nkb2 <= 23;
+        }
+        if (want) {
             tsr_bank *mb = const_cast<tsr_bank *>(bank);
             int sb = bank->fast[4] ? TSR_OK : tsr_fast_bank_build(ctx, mb, 4);
             if (sb == TSR_OK) sb = tsr_launch_tap2_bank(ctx, bank, cp, d_all ? nullptr : cp->d_scores, d_all ? nullptr : cp->d_ids, d_all);

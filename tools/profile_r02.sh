@@ -24,7 +24,8 @@ bench)
   kstats bench_exact bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-modes --mode exact || exit 1 ;;
 traffic)   # HBM bytes per launch on a working set of 16 corpus copies (1.2 GB >> 256 MiB of Infinity Cache)
   pmc traffic_fetch FETCH_SIZE bench.py --steps 3 --warmup 1 --replicas 16 --no-cpu-baseline --no-modes --mode fast && \
-  pmc traffic_write WRITE_SIZE bench.py --steps 3 --warmup 1 --replicas 16 --no-cpu-baseline --no-modes --mode fast || exit 1 ;;
+  pmc traffic_write WRITE_SIZE bench.py --steps 3 --warmup 1 --replicas 16 --no-cpu-baseline --no-modes --mode fast && \
+  python3 tools/traffic_json.py gpurun_out/r02_pmc_traffic_fetch.txt gpurun_out/r02_pmc_traffic_write.txt fast gpurun_out/r02_traffic_fast.json || exit 1 ;;
 sq)
   pmc sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" bench.py --steps 3 --warmup 1 --replicas 16 --no-cpu-baseline --no-modes --mode fast && \
   pmc sq2 "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM" bench.py --steps 3 --warmup 1 --replicas 16 --no-cpu-baseline --no-modes --mode fast || exit 1 ;;
