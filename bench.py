@@ -216,12 +216,11 @@ def roofline_of(mode, per_launch_s, frames, traffic):
     # ridge, and each algorithmic MAC costs 2 (3) int8 limb-MACs, so the matrix cores bind
     tops = ALG_FLOPS / per_launch_s / 1e12
     limbs = 2 if mode == "fast" else 3
-    # which two-limb kernel tsr_corpus_score picks (tsr_api.hip): the tap-pair kernel when the bank is one column
-    # group (sum of ceil(L/2) <= 128) and the resident rows are an odd number (<= 23) of 16-byte slots
+    # which two-limb kernel tsr_corpus_score picks (tsr_api.hip): the tap-pair kernel when the resident rows are an
+    # odd number (<= 23) of 16-byte slots
     dp16 = math.ceil(D / 16)
     forced = os.environ.get("TSR_FASTK", "")[:1]
-    tap_pair = mode == "fast" and (forced == "t" or (forced != "o" and CFG["M"] * math.ceil(CFG["L"] / 2) <= 128
-                                                     and dp16 % 2 == 1 and dp16 <= 23))
+    tap_pair = mode == "fast" and (forced == "t" or (forced != "o" and dp16 % 2 == 1 and dp16 <= 23))
     if tap_pair:   # K = two resident rows of 16 * dp16 bytes per tap pair; odd L would add half a tap per template
         kpad = (16 * dp16) / D * (2 * math.ceil(CFG["L"] / 2)) / CFG["L"]
         kpad_what = "K padding (%d/%d; tap-pair kernel)" % (16 * dp16, D)

@@ -410,9 +410,10 @@ int tsr_launch_tap2_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, flo
     const int64_t min_rows = 128;
     nseg = (int)std::max<int64_t>(1, std::min<int64_t>(nseg, (P + min_rows - 1) / min_rows));
     int spx = 0;
-    if (fb->G > 1 && fb->G <= 2 * (ctx->cus / 8)) {
+    if (fb->G > 1 && fb->G <= ctx->cus / 8) {  // (one workgroup per CU: 256 registers per wave)
         const char *e = getenv("TSR_XCD_MAP");
-        const int want = (2 * (ctx->cus / 8)) / fb->G;
+        int want = (ctx->cus / 8) / fb->G;
+        if (const char *m = getenv("TSR_TAP2_SPXMUL")) want *= std::max(1, atoi(m));  // (experiments)
         if (!(e && e[0] == '0') && want >= 1 && (int64_t)8 * want * min_rows * 2 <= P) {
             spx = want;
             nseg = 8 * spx;

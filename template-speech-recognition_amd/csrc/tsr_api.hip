@@ -529,19 +529,16 @@ static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp,
         if ((int64_t)bank->Lmax * bank->D > TSR_FAST_W24_ABOVE_TAPS) flags |= TSR_W24;
     }
     if (flags == TSR_FAST && !bank->tap2_unsupported) {
-        // Two limbs on narrow feature rows: the tap-pair kernel (detect_mfma_tap2.inc: two taps folded into K, half the
-        // skew emission per matrix instruction) where the whole bank is one column group -- sum of ceil(L_m / 2) <= 128
-        // columns, rows of an odd number (<= 23) of 16-byte slots; config 2: 7 % faster than the interleaved kernel.
-        // With several column groups it is the slower one (0.95 vs 0.40 ms on config 4), so those banks stay on the
-        // interleaved kernel.  TSR_FASTK=tap2 / TSR_FASTK=old force one or the other (read per launch: A/B
-        // measurements inside one process).
+        // Two limbs on narrow feature rows (an odd number <= 23 of 16-byte slots: the edge features of BASELINE
+        // configs 1, 2 and 4): the tap-pair kernel (detect_mfma_tap2.inc: two taps folded into K, half the skew
+        // emission per matrix instruction) -- config 2: 7 % faster than the interleaved kernel, config 4: 10 %.
+        // Wider rows, and filters too long for its LDS ring, stay on the interleaved kernel.  TSR_FASTK=tap2 /
+        // TSR_FASTK=old force one or the other (read per launch: A/B measurements inside one process).
         const char *e = getenv("TSR_FASTK");
         bool want = e && e[0] == 't';
         if (!e || (e[0] != 't' && e[0] != 'o')) {
-            int64_t cols = 0;
-            for (int32_t l : bank->L) cols += (l + 1) / 2;
             const int nkb2 = cp->Dp / 16;
-            want = cols <= 128 && (nkb2 & 1) && nkb2 <= 23;
+            want = (nkb2 & 1) && nkb2 <= 23;
         }
         if (want) {
             tsr_bank *mb = const_cast<tsr_bank *>(bank);
