@@ -1326,3 +1326,39 @@ def test_exact_bank_with_subnormal_weights_stays_on_the_vector_kernel(mods, orac
     s, a = bank.score(c["feats"], c["offsets"], flags=tsr_hip.TSR_EXACT)
     assert np.array_equal(s, so) and np.array_equal(a, ao)
     assert np.any(s != 0)
+
+
+def test_padding_columns_do_not_serialise_the_ring(mods, oracle):
+    """A regression guard with a wide margin, not a benchmark: config 2b (272 tap columns) ends in a column group that is
+    mostly padding.  When padding lanes all added into one spare ring cell (same-address LDS atomics serialise) its pass
+    took 10x config 2's (364 vs 36 us); with per-lane spare cells / silent padding lanes it takes 2x (two column
+    groups).  Both two-limb kernels, same corpus size."""
+    import os
+    tsr_hip = mods[3]
+    from tsr_hip import synth
+    ctx = tsr_hip.default_ctx()
+
+    def per_launch(c, n=20):
+        P = int(c["offsets"][-1])
+        bank = tsr_hip.Bank(c["bank"])
+        dc = tsr_hip.Corpus(c["feats"].reshape(P, -1), c["offsets"])
+        for _ in range(3):
+            dc.score(bank, tsr_hip.TSR_FAST)
+        ctx.sync()
+        best = 1e9
+        for _ in range(3):
+            ctx.timer_start()
+            for _ in range(n):
+                dc.score(bank, tsr_hip.TSR_FAST)
+            best = min(best, ctx.timer_stop() / n)
+        return best
+
+    c2 = synth.corpus(2, N=1000, T=200, F=45, E=8, M=8, L=32)
+    c2b = synth.corpus(2, N=1000, T=200, F=45, E=8, M=8, L=[20, 24, 28, 32, 36, 40, 44, 48])
+    for kernel in ("tap2", "old"):
+        os.environ["TSR_FASTK"] = kernel
+        try:
+            t2, t2b = per_launch(c2), per_launch(c2b)
+        finally:
+            del os.environ["TSR_FASTK"]
+        assert t2b < 5.0 * t2, (kernel, t2, t2b)
