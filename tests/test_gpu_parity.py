@@ -1240,10 +1240,11 @@ def test_bf16_unsupported_geometry_falls_back_to_exact(mods, oracle):
 
 
 def test_tap_pair_kernel_parity(mods, oracle):
-    """TSR_FASTK=tap2 selects the two-taps-in-K, alternating-segment variant of the two-limb bank pass
-    (csrc/detect_mfma_tap2.inc; an experiment kept for A/B measurements): the same exact integer sums as the default
-    kernel -- identical scores and ids at the benchmark's size and on ragged geometry, one float32 rounding apart when
-    there are several column groups."""
+    """The two two-limb kernels against each other: TSR_FASTK=tap2 is the two-taps-in-K, alternating-segment kernel
+    (csrc/detect_mfma_tap2.inc; the default on narrow feature rows), TSR_FASTK=old the interleaved one
+    (csrc/detect_mfma_kernel.inc).  Both sum the same fixed-point integers exactly -- identical scores and ids where a
+    bank is one column group in both, one float32 rounding apart where templates are cut into fragments at different
+    columns -- at the benchmark's size, on ragged geometry, with 64 templates and on a tiny case."""
     import os
     tsr_hip = mods[3]
     from tsr_hip import synth
@@ -1258,23 +1259,21 @@ def test_tap_pair_kernel_parity(mods, oracle):
         P = int(c["offsets"][-1])
         bank = tsr_hip.Bank(c["bank"])
         dc = tsr_hip.Corpus(c["feats"].reshape(P, -1), c["offsets"])
-        dc.score(bank, tsr_hip.TSR_FAST)
-        want = dc.download()
-        want_all = dc.score_all(bank, tsr_hip.TSR_FAST)
-        os.environ["TSR_FASTK"] = "tap2"
-        try:
-            dc.score(bank, tsr_hip.TSR_FAST)
-            got = dc.download()
-            got_all = dc.score_all(bank, tsr_hip.TSR_FAST)
-        finally:
-            del os.environ["TSR_FASTK"]
-        if bank.M <= 8:
+        res = {}
+        for kernel in ("old", "tap2"):
+            os.environ["TSR_FASTK"] = kernel
+            try:
+                dc.score(bank, tsr_hip.TSR_FAST)
+                res[kernel] = dc.download() + (dc.score_all(bank, tsr_hip.TSR_FAST),)
+            finally:
+                del os.environ["TSR_FASTK"]
+        want, got = res["old"], res["tap2"]
+        taps = sum(W.shape[0] for W, _ in c["bank"])
+        if taps <= 256:   # one column group in both kernels (256 tap columns / 128 tap-pair columns)
             assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
-            assert np.array_equal(got_all, want_all)
+            assert np.array_equal(got[2], want[2])
         else:
-            # several column groups: a template cut at a group boundary is the float sum of two exact partial
-            # sums, and the two kernels cut at different columns -- one float32 rounding apart
-            assert rel_err(got[0], want[0]) <= 1e-6 and rel_err(got_all, want_all) <= 1e-6
+            assert rel_err(got[0], want[0]) <= 1e-6 and rel_err(got[2], want[2]) <= 1e-6
         dc.score(bank, tsr_hip.TSR_EXACT)
         assert rel_err(got[0], dc.download()[0]) <= TOL
 
