@@ -49,6 +49,20 @@ __global__ __launch_bounds__(256) void frag_epilogue_kernel(
     if (ids) ids[p] = besti;
 }
 
+// Several column groups of whole templates: every group's workgroups have taken the max of their keys
+// (orderable(score) << 32 | ~template id) into keys[p]; scores and ids out (the decode of the kernels' phase C).
+__global__ __launch_bounds__(256) void key_decode_kernel(const unsigned long long *__restrict__ keys, int64_t P,
+                                                         float *__restrict__ scores, int32_t *__restrict__ ids)
+{
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const unsigned long long key = keys[p];
+    unsigned u = (unsigned)(key >> 32);
+    u ^= (~(unsigned)((int)u >> 31)) | 0x80000000u;
+    if (scores) reinterpret_cast<unsigned *>(scores)[p] = u;
+    if (ids) ids[p] = (int)~(unsigned)key;
+}
+
 struct FastBank {
     int NL = 0;  // int8 limbs per weight
     int NKB = 0, KS = 0, CT = 0, G = 0, nkb_total = 0, n_coltiles = 0, n_frag = 0;
@@ -59,6 +73,8 @@ struct FastBank {
     int32_t *d_frag_ptr = nullptr, *d_frag_idx = nullptr;
     SlotMeta *d_slots = nullptr;
     int max_slots = 0;
+    bool packed = false;   // tap pairs: every template lies inside one column group (no fragments: a group's
+                           // slots are whole templates, several groups meet in a global max-key array)
 };
 
 template <typename T>
@@ -143,6 +159,54 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int kind)
     auto ncols = [&](int L) { return tap2 ? (L + 1) / 2 : L; };
     int64_t C = 0;
     for (int m = 0; m < M; ++m) C += ncols(bank->L[m]);
+    // Column start of every template.  By default the templates follow each other and a column group is simply the
+    // next CT tiles of columns (templates cut at group boundaries become fragments, summed by frag_epilogue_kernel).
+    // Tap pairs with several groups: whole templates are packed into the groups (first fit, longest first, ids
+    // ascending inside a group), the rest of a group is padding -- no fragments, no fragment traffic, the groups meet
+    // in a max-key array -- as long as that costs no more than one group over the contiguous layout.
+    std::vector<int64_t> col0((size_t)M, 0);
+    bool packed = false;
+    {
+        const int64_t gcols = (int64_t)CT * 32;
+        const int G_contig = (int)((C + gcols - 1) / gcols);
+        if (tap2 && G_contig > 1) {
+            std::vector<int> order((size_t)M);
+            for (int m = 0; m < M; ++m) order[(size_t)m] = m;
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return bank->L[x] > bank->L[y]; });
+            std::vector<int64_t> fill;
+            std::vector<int> grp_of((size_t)M, -1);
+            bool ok = true;
+            for (int m : order) {
+                const int64_t n = ncols(bank->L[m]);
+                if (n > gcols) {
+                    ok = false;
+                    break;
+                }
+                size_t g = 0;
+                while (g < fill.size() && fill[g] + n > gcols) ++g;
+                if (g == fill.size()) fill.push_back(0);
+                grp_of[(size_t)m] = (int)g;
+                fill[g] += n;
+            }
+            if (ok && (int)fill.size() <= G_contig + G_contig / 8) {  // (at most an eighth more groups than cutting templates would need)
+                packed = true;
+                std::vector<int64_t> next(fill.size());
+                for (size_t g = 0; g < fill.size(); ++g) next[g] = (int64_t)g * gcols;
+                for (int m = 0; m < M; ++m) {  // ids ascending inside a group
+                    col0[(size_t)m] = next[(size_t)grp_of[(size_t)m]];
+                    next[(size_t)grp_of[(size_t)m]] += ncols(bank->L[m]);
+                }
+                C = (int64_t)fill.size() * gcols;  // (padding columns between the groups' templates included)
+            }
+        }
+        if (!packed) {
+            int64_t c0 = 0;
+            for (int m = 0; m < M; ++m) {
+                col0[(size_t)m] = c0;
+                c0 += ncols(bank->L[m]);
+            }
+        }
+    }
     const int n_coltiles = (int)((C + 31) / 32);
     const int G = (n_coltiles + CT - 1) / CT;
 
@@ -153,10 +217,11 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int kind)
     std::vector<double> inv_scale(M);
     std::vector<int8_t> limbs(bf ? 0 : (size_t)NL * C * (tap2 ? K2 : D));   // [limb][column][d]  (tap pairs: [b Dp + d])
     std::vector<uint16_t> blimbs(bf ? (size_t)NL * C * D : 0);   // bf16: hi (and lo = rn(W - hi))
-    std::vector<int32_t> col_tmpl((size_t)C), col_tau_v((size_t)C);
+    std::vector<int32_t> col_tmpl((size_t)C, -1), col_tau_v((size_t)C, 0);   // (-1: a padding column of the packed layout)
     {
-        int64_t woff = 0, c0 = 0;
+        int64_t woff = 0;
         for (int m = 0; m < M; ++m) {
+            const int64_t c0 = col0[(size_t)m];
             const int64_t n = (int64_t)bank->L[m] * D;
             const float *w = bank->W_cat.data() + woff;
             float mx = 0.0f;
@@ -215,7 +280,6 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int kind)
                 }
             }
             woff += n;
-            c0 += ncols(bank->L[m]);
         }
     }
     // ---- column groups -> fragment slots ------------------------------------------------------
@@ -229,11 +293,12 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int kind)
     std::vector<int32_t> g_nslots(G, 0);
     std::vector<std::vector<int>> frags_of(M);
     int max_slots = 0, n_frag = 0;
-    const bool single = (n_phase == 1 && G == 1);
+    const bool single = (n_phase == 1 && (G == 1 || packed));
     for (int g = 0; g < G; ++g) {
         int nslots = 0, last_m = -1;
         for (int64_t c = (int64_t)g * CT * 32; c < std::min<int64_t>(C, (int64_t)(g + 1) * CT * 32); ++c) {
             const int m = col_tmpl[(size_t)c];
+            if (m < 0) continue;
             if (m != last_m) {
                 if (nslots == kMaxSlots) {
                     tsr_set_error("TSR_FAST: more than %d templates share one column group", kMaxSlots);
@@ -253,7 +318,7 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int kind)
             int sidx = -1, last_m = -1;
             for (int64_t c = (int64_t)g * CT * 32; c < std::min<int64_t>(C, (int64_t)(g + 1) * CT * 32); ++c) {
                 const int m = col_tmpl[(size_t)c];
-                if (m == last_m) continue;
+                if (m < 0 || m == last_m) continue;
                 last_m = m;
                 ++sidx;
                 SlotMeta &sm = slots[((size_t)ph * G + g) * kMaxSlots + sidx];
@@ -310,6 +375,7 @@ int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int kind)
     fb->max_slots = max_slots;
     fb->n_phase = n_phase;
     fb->wl_phase = wl_phase;
+    fb->packed = packed;
     bank->fast[kind] = fb;
     int s = upload(ctx, &fb->d_Wl, Wl);
     if (s == TSR_OK) s = upload(ctx, &fb->d_col_slot, col_slot);
@@ -420,9 +486,16 @@ int tsr_launch_tap2_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, flo
         }
     }
     TSR_TRY(build_plan(ctx, cp, nseg, bank->Lmax));
-    const bool fragments = fb->G > 1;
+    // several column groups: template fragments summed by frag_epilogue_kernel, or -- whole templates packed into the
+    // groups -- per-template rows written directly (all-scores pass) / a max-key array the groups meet in
+    const bool fragments = fb->G > 1 && !fb->packed;
+    const bool keyed = fb->G > 1 && fb->packed && !d_all;
     void *raw_frag = nullptr;
     if (fragments) TSR_TRY(tsr_scratch(ctx, 0, (size_t)fb->n_frag * P * sizeof(float), &raw_frag));
+    if (keyed) {
+        TSR_TRY(tsr_scratch(ctx, 0, (size_t)P * sizeof(unsigned long long), &raw_frag));
+        TSR_HIP(hipMemsetAsync(raw_frag, 0, (size_t)P * sizeof(unsigned long long), ctx->stream));
+    }
     const int grid = nseg * fb->G;
     FastArgs a;
     memset(&a, 0, sizeof a);
@@ -455,6 +528,8 @@ int tsr_launch_tap2_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, flo
     a.dbg = d_dbg;
     if (fragments) {
         a.raw_frag = (float *)raw_frag;
+    } else if (keyed) {
+        a.keys = (unsigned long long *)raw_frag;
     } else {
         a.scores = d_scores;
         a.ids = d_ids;
@@ -497,6 +572,11 @@ int tsr_launch_tap2_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, flo
         hipLaunchKernelGGL(frag_epilogue_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const float *)raw_frag, P, bank->M, fb->d_frag_ptr, fb->d_frag_idx, bank->d_L, bank->d_cf,
                            cp->d_utt_end, d_scores, d_ids, d_all);
+        TSR_HIP(hipGetLastError());
+    }
+    if (keyed) {
+        hipLaunchKernelGGL(key_decode_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const unsigned long long *)raw_frag, P, d_scores, d_ids);
         TSR_HIP(hipGetLastError());
     }
     return TSR_OK;
