@@ -333,18 +333,23 @@ int tsr_magnitude_features(tsr_ctx *ctx, const double *S, int64_t F0, int64_t T,
 int tsr_corpus_weighted_sums(tsr_ctx *ctx, const tsr_corpus *corpus, const float *weights, int64_t K, float *out);
 
 /* ---- Bernoulli-mixture EM on a resident data matrix (next: SURVEY 8(f) N4) ------
- * bernoulli_mixture.py:263-285 (_compute_loglikelihoods) and :175-182 (M_step).
- * `data` is a corpus of one-frame utterances (the 0/1 data matrix [N, D]); `bank` holds one one-tap
- * filter per mixture component: W_k = log T_k - log(1 - T_k), c_k = sum_d log(1 - T_k[d]), so that
- * the bank score of row n is log P(x_n | k) (get_template_loglikelihoods, :287-291).
- * tsr_mixture_e_step: scores (TSR_FAST | TSR_W24) -> per row the max-shifted log-sum-exp over
- *   score + log_weights[k] -> *loglikelihood (sum over rows, f64, reproducible order) and the posterior
- *   component probabilities f32 [N, K] (one-hot on the first best score when hard_assignment, :278-281),
- *   which STAY ON THE DEVICE for the M-step; `affinities` (host, [N*K]) may be NULL.
+ * bernoulli_mixture.py:263-291 (_compute_loglikelihoods, get_template_loglikelihoods) and :175-182 (M_step).
+ * `data` is a corpus of one-frame utterances (the 0/1 data matrix [N, D]); component k is given by its log-odds row
+ * log_odds[k] = log T_k - log(1 - T_k) (f32 [K, D]) and consts[k] = sum_d log(1 - T_k[d]) (f64), so that
+ *     log P(x_n | k) = consts[k] + sum_d x[n,d] log_odds[k,d]
+ * (f32 products and partial sums, f64 across the lanes and for the constant, one rounding to f32: like the reference's
+ * float32 BLAS product not a defined summation order, agreement to f32 rounding).
+ * tsr_mixture_scores: those scores, f32 [K, N] (get_template_loglikelihoods transposed).
+ * tsr_mixture_e_step: scores -> per row the max-shifted log-sum-exp over score + log_weights[k] -> *loglikelihood
+ *   (sum over rows, f64, reproducible order) and the posterior component probabilities f32 [N, K] (one-hot on the
+ *   first best score when hard_assignment, :278-281), which STAY ON THE DEVICE for the M-step; `affinities`
+ *   (host, [N*K]) may be NULL.
  * tsr_mixture_m_step: weights[k] = mean_n a[n,k] (f64 [K]) and sums[k,d] = sum_n a[n,k] x[n,d]
  *   (f32 [K*D], fixed summation order) from the posteriors of the latest e-step. */
-int tsr_mixture_e_step(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *data, const double *log_weights,
-                       int32_t hard_assignment, double *loglikelihood, float *affinities);
+int tsr_mixture_scores(tsr_ctx *ctx, const tsr_corpus *data, const float *log_odds, const double *consts, int32_t K,
+                       float *scores);
+int tsr_mixture_e_step(tsr_ctx *ctx, tsr_corpus *data, const float *log_odds, const double *consts, int32_t K,
+                       const double *log_weights, int32_t hard_assignment, double *loglikelihood, float *affinities);
 int tsr_mixture_m_step(tsr_ctx *ctx, tsr_corpus *data, double *weights, float *sums);
 /* the posteriors of the latest e-step, f32 [N, K] */
 int tsr_corpus_download_affinities(tsr_ctx *ctx, const tsr_corpus *data, float *affinities);

@@ -412,6 +412,60 @@ __global__ __launch_bounds__(kThreads) void mixture_estep_kernel(const float *__
 }
 }  // namespace
 
+// log P(x_n | k) = c_k + sum_d x[n,d] odds[k,d] for the rows of a resident 0/1 data matrix: a [N, D] x [D, K] product
+// with K of the order of ten -- far too narrow for the bank kernels (K one-tap "templates" are K of 256 columns of a
+// workgroup's matrix tiles, and every EM iteration would re-encode the bank on the host).  One wave per row: the lanes
+// stride over the features four at a time (one dword of 0/1 bytes, a float4 of each component's log-odds row), eight
+// components per pass, f32 partial sums per lane, f64 across the lanes and for + c_k, one rounding to f32.  The tables
+// (K x D floats, a few hundred KB) are shared by all waves through L1/L2.
+namespace {
+__global__ __launch_bounds__(256) void mixture_scores_kernel(const uint8_t *__restrict__ X, int64_t P, int D, int Dp,
+                                                             const float *__restrict__ odds /*[K][Dq]*/, int Dq,
+                                                             const double *__restrict__ cst /*[K]*/, int K,
+                                                             float *__restrict__ scores /*[K][P]*/)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t n = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (n >= P) return;  // (whole wave)
+    const uint32_t *xr = reinterpret_cast<const uint32_t *>(X + n * Dp);
+    const int nd4 = Dq >> 2;  // features in fours (rows and tables are zero padded up to Dq)
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        const int kn = min(8, K - k0);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = lane; i < nd4; i += 64) {
+            const uint32_t x = xr[i];
+            const float x0 = (float)(x & 1u), x1 = (float)((x >> 8) & 1u), x2 = (float)((x >> 16) & 1u), x3 = (float)(x >> 24);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < kn) {
+                    const float4 w = *reinterpret_cast<const float4 *>(odds + (int64_t)(k0 + k) * Dq + 4 * i);
+                    acc[k] = __builtin_fmaf(x0, w.x, acc[k]);
+                    acc[k] = __builtin_fmaf(x1, w.y, acc[k]);
+                    acc[k] = __builtin_fmaf(x2, w.z, acc[k]);
+                    acc[k] = __builtin_fmaf(x3, w.w, acc[k]);
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            double v = (double)acc[k];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+            if (k < kn && lane == 0) scores[(int64_t)(k0 + k) * P + n] = (float)(v + cst[k0 + k]);
+        }
+    }
+}
+}  // namespace
+
+int tsr_launch_mixture_scores(tsr_ctx *ctx, const uint8_t *d_X, int64_t P, int D, int Dp, const float *d_odds, int Dq,
+                              const double *d_c, int K, float *d_scores)
+{
+    if (P <= 0) return TSR_OK;
+    hipLaunchKernelGGL(mixture_scores_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, ctx->stream, d_X, P, D, Dp, d_odds, Dq, d_c,
+                       K, d_scores);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+
 int tsr_launch_mixture_estep(tsr_ctx *ctx, const float *d_scores, int64_t P, int K, const double *d_log_w, int hard,
                              float *d_aff, double *d_blk, int *n_blocks)
 {

@@ -1220,16 +1220,50 @@ TSR_API int tsr_corpus_weighted_sums(tsr_ctx *ctx, const tsr_corpus *cp, const f
 }
 
 // ---- Bernoulli-mixture EM on a resident data matrix (bernoulli_mixture.py:108-291) --------
-// E-step: component scores by the bank pass (23-bit MFMA weights), then log marginals and posteriors on the
-// device; the posteriors stay there for the M-step.  `bank` holds, per component k, the one-tap filter
-// log T_k - log(1 - T_k) with c_k = sum_d log(1 - T_k[d]) (the data points are one-frame utterances).
-TSR_API int tsr_mixture_e_step(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, const double *log_weights,
-                               int32_t hard_assignment, double *loglikelihood, float *affinities)
+// Component scores log P(x_n | k) = consts[k] + sum_d x[n,d] log_odds[k,d] of the rows of a resident data matrix
+// into a device array [K][P]: the tables go up zero padded to the resident row stride, one wave per row multiplies
+// (classify.hip: mixture_scores_kernel).
+static int mixture_scores_device(tsr_ctx *ctx, const tsr_corpus *cp, const float *log_odds, const double *consts, int K, float *d_all)
 {
-    TSR_REQUIRE(ctx && bank && cp && log_weights && loglikelihood, "tsr_mixture_e_step: null pointer");
-    TSR_REQUIRE(bank->Lmax == 1, "tsr_mixture_e_step: mixture components are one-tap filters (Lmax=%d)", bank->Lmax);
+    const int64_t D = cp->D;
+    const int Dq = cp->Dp;
+    std::vector<float> tab((size_t)K * Dq, 0.0f);
+    for (int k = 0; k < K; ++k) {
+        for (int64_t d = 0; d < D; ++d) TSR_REQUIRE(std::isfinite(log_odds[(size_t)k * D + d]), "mixture: log-odds value (%d, %lld) is not finite", k, (long long)d);
+        TSR_REQUIRE(std::isfinite(consts[k]), "mixture: constant %d is not finite", k);
+        memcpy(tab.data() + (size_t)k * Dq, log_odds + (size_t)k * D, (size_t)D * sizeof(float));
+    }
+    void *d_tab = nullptr, *d_c = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_W, tab.size() * sizeof(float), &d_tab));
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX, (size_t)K * 8, &d_c));
+    TSR_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    TSR_HIP(hipMemcpyAsync(d_c, consts, (size_t)K * 8, hipMemcpyHostToDevice, ctx->stream));
+    TSR_TRY(tsr_launch_mixture_scores(ctx, cp->d_feats, cp->P, (int)D, cp->Dp, (const float *)d_tab, Dq, (const double *)d_c, K, d_all));
+    TSR_HIP(hipStreamSynchronize(ctx->stream));  // (the host staging vector dies here)
+    return TSR_OK;
+}
+
+TSR_API int tsr_mixture_scores(tsr_ctx *ctx, const tsr_corpus *cp, const float *log_odds, const double *consts, int32_t K,
+                               float *scores)
+{
+    TSR_REQUIRE(ctx && cp && log_odds && consts && (scores || cp->P == 0), "tsr_mixture_scores: null pointer");
+    TSR_REQUIRE(K >= 1 && K <= 65535, "tsr_mixture_scores: K=%d out of range", K);
+    if (cp->P == 0) return TSR_OK;
+    TSR_HIP(hipSetDevice(ctx->device));
+    void *d_all = nullptr;
+    TSR_TRY(tsr_scratch(ctx, SLOT_OUT, (size_t)K * cp->P * sizeof(float), &d_all));
+    TSR_TRY(mixture_scores_device(ctx, cp, log_odds, consts, K, (float *)d_all));
+    return tsr_download(ctx, scores, d_all, (size_t)K * cp->P * sizeof(float));
+}
+
+// E-step: component scores, then log marginals and posteriors on the device; the posteriors stay there for the
+// M-step.  log_odds[k] = log T_k - log(1 - T_k), consts[k] = sum_d log(1 - T_k[d]).
+TSR_API int tsr_mixture_e_step(tsr_ctx *ctx, tsr_corpus *cp, const float *log_odds, const double *consts, int32_t K,
+                               const double *log_weights, int32_t hard_assignment, double *loglikelihood, float *affinities)
+{
+    TSR_REQUIRE(ctx && cp && log_odds && consts && log_weights && loglikelihood, "tsr_mixture_e_step: null pointer");
+    TSR_REQUIRE(K >= 1 && K <= 65535, "tsr_mixture_e_step: K=%d out of range", K);
     const int64_t P = cp->P;
-    const int K = bank->M;
     *loglikelihood = 0.0;
     cp->aff_K = K;
     cp->aff_colsum.assign((size_t)K, 0.0);
@@ -1245,9 +1279,9 @@ TSR_API int tsr_mixture_e_step(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *c
     }
     void *d_all = nullptr, *d_lw = nullptr, *d_blk = nullptr;
     TSR_TRY(tsr_scratch(ctx, SLOT_OUT, (size_t)K * P * sizeof(float), &d_all));
-    TSR_TRY(corpus_score_impl(ctx, bank, cp, TSR_FAST | TSR_W24, (float *)d_all));
+    TSR_TRY(mixture_scores_device(ctx, cp, log_odds, consts, K, (float *)d_all));
     const int blocks = (int)((P + 255) / 256);
-    TSR_TRY(tsr_scratch(ctx, SLOT_AUX, (size_t)K * 8, &d_lw));
+    TSR_TRY(tsr_scratch(ctx, SLOT_AUX, (size_t)K * 8, &d_lw));  // (the constants that lived here are consumed)
     TSR_TRY(tsr_scratch(ctx, SLOT_AUX2, (size_t)blocks * (K + 1) * 8, &d_blk));
     TSR_HIP(hipMemcpyAsync(d_lw, log_weights, (size_t)K * 8, hipMemcpyHostToDevice, ctx->stream));
     int nb = 0;

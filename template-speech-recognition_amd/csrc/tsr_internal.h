@@ -189,6 +189,8 @@ int tsr_launch_window_peak_max(tsr_ctx *ctx, const float *d_v, const int64_t *d_
                                const int64_t *d_starts, const int64_t *d_ends, int64_t W, float *d_out);
 int tsr_launch_mstep(tsr_ctx *ctx, const uint8_t *d_X, int64_t P, int D, int Dp, const float *d_aff, int K,
                      float *d_part, int S, float *d_out);
+int tsr_launch_mixture_scores(tsr_ctx *ctx, const uint8_t *d_X, int64_t P, int D, int Dp, const float *d_odds, int Dq,
+                              const double *d_c, int K, float *d_scores);
 int tsr_launch_mixture_estep(tsr_ctx *ctx, const float *d_scores, int64_t P, int K, const double *d_log_w, int hard,
                              float *d_aff, double *d_blk, int *n_blocks);
 int tsr_launch_link_partition(tsr_ctx *ctx, const int32_t *d_times, const int32_t *d_lengths, int64_t n, uint8_t *d_part);

@@ -3,9 +3,9 @@
 Same public surface as the reference's bernoulli_mixture.BernoulliMixture (constructor arguments, attribute
 names, run_EM / M_step / _compute_loglikelihoods / get_template_loglikelihoods / set_templates / save,
 bernoulli_mixture.py:73-312), different inside: the 0/1 data matrix is uploaded once and stays resident; an
-E-step is ONE library call (tsr_mixture_e_step) that scores every row against every component on the matrix
-cores -- log P(x_n | k) = sum_d log(1-T_k[d]) + sum_d x[n,d] (log T_k - log(1-T_k))[d] is the bank score of a
-one-frame utterance, exact integer accumulation of 23-bit fixed-point weights -- and finishes on the device
+E-step is ONE library call (tsr_mixture_e_step) that scores every row against every component --
+log P(x_n | k) = sum_d log(1-T_k[d]) + sum_d x[n,d] (log T_k - log(1-T_k))[d], one wave per row, the K log-odds
+rows shared through the caches -- and finishes on the device
 with the max-shifted log-sum-exp, the log-likelihood and the posterior component probabilities
 (:263-285).  The posteriors never leave the device between the E-step and the M-step (tsr_mixture_m_step:
 the column means and affinities^T . data_mat of :175-179); `affinities` is fetched only when somebody reads it.
@@ -121,28 +121,28 @@ class BernoulliMixture:
                                       weights=self.weights)
 
     # ---- EM (:108-184, :263-291) -----------------------------------------------------------------------------------
-    def _component_bank(self):
-        """One one-tap filter per component: W_k = log T_k - log(1 - T_k), c_k = sum_d log(1 - T_k[d])."""
+    def _component_tables(self):
+        """Per component k the log-odds row log T_k - log(1 - T_k) (f32 [K, D]) and c_k = sum_d log(1 - T_k[d]) (f64)."""
         lt = np.asarray(self.log_templates, np.float64).reshape(self.num_mix, self.data_length)
         lit = np.asarray(self.log_invtemplates, np.float64).reshape(self.num_mix, self.data_length)
-        odds = (lt - lit).astype(np.float32)
-        return api.Bank([(odds[k:k + 1], float(lit[k].sum())) for k in range(self.num_mix)], ctx=self._ctx)
+        return np.ascontiguousarray((lt - lit).astype(np.float32)), np.ascontiguousarray(lit.sum(axis=1))
 
     def get_template_loglikelihoods(self):
         """[num_data, num_mix]: log P(x_n | component k) (:287-291), one pass over the resident data matrix."""
-        bank = self._component_bank()
-        return self._corpus.score_all(bank, api.TSR_FAST | api.TSR_W24).T.astype(np.float64)
+        odds, consts = self._component_tables()
+        out = np.empty((self.num_mix, self.num_data), np.float32)
+        check(lib().tsr_mixture_scores(self._ctx._h, self._corpus._h, ptr(odds), ptr(consts), self.num_mix, ptr(out)))
+        return out.T.astype(np.float64)
 
     def _compute_loglikelihoods(self):
         """E-step (:263-285): returns the data log-likelihood under the current tables and weights and leaves the
         posteriors (one-hot on the best-scoring component with hard assignment) on the device."""
-        bank = self._component_bank()
+        odds, consts = self._component_tables()
         with np.errstate(divide='ignore'):
             log_w = np.log(np.asarray(self.weights, np.float64))
         total = C.c_double()
-        check(lib().tsr_mixture_e_step(self._ctx._h, bank._h, self._corpus._h, ptr(np.ascontiguousarray(log_w)),
-                                       int(bool(self.hard_assignment)), C.byref(total), None))
-        bank.close()
+        check(lib().tsr_mixture_e_step(self._ctx._h, self._corpus._h, ptr(odds), ptr(consts), self.num_mix,
+                                       ptr(np.ascontiguousarray(log_w)), int(bool(self.hard_assignment)), C.byref(total), None))
         self._aff, self._aff_on_device = None, True
         return float(total.value)
 

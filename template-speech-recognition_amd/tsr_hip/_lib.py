@@ -58,7 +58,8 @@ SIGNATURES = {
     "tsr_spread_edgemap": [_p, _p, _p, _i32, _i64, _p, _i32],
     "tsr_magnitude_features": [_p, _p, _i64, _i64, _i32, _i32, C.c_double, _i32, _i32, _i32, _i32, _p],
     "tsr_corpus_weighted_sums": [_p, _p, _p, _i64, _p],
-    "tsr_mixture_e_step": [_p, _p, _p, _p, _i32, C.POINTER(C.c_double), _p],
+    "tsr_mixture_scores": [_p, _p, _p, _p, _i32, _p],
+    "tsr_mixture_e_step": [_p, _p, _p, _p, _i32, _p, _i32, C.POINTER(C.c_double), _p],
     "tsr_mixture_m_step": [_p, _p, _p, _p],
     "tsr_corpus_download_affinities": [_p, _p, _p],
     "tsr_parts_create": [_p, _p, _p, _i64, _i64, _i64, _i64, _pp],

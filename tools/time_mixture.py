@@ -16,7 +16,7 @@ t2 = time.perf_counter()
 ref = np.dot(X, mix.log_templates.T) + np.dot(1 - X, mix.log_invtemplates.T)
 t3 = time.perf_counter()
 ref64 = X.astype(np.float64) @ mix.log_templates.astype(np.float64).T + (1 - X.astype(np.float64)) @ mix.log_invtemplates.astype(np.float64).T
-print("E-step scoring, %d examples x D=%d x %d components: device %.2f ms (bank build + launch + download), NumPy float32 %.1f ms"
+print("E-step scoring, %d examples x D=%d x %d components: device %.2f ms (table upload + kernel + download), NumPy float32 %.1f ms"
       % (N, mix.data_length, K, (t1 - t0) * 1e3, (t3 - t2) * 1e3))
 print("max relative deviation from the float64 value: device %.2e, NumPy float32 %.2e"
       % (np.max(np.abs(got - ref64) / np.abs(ref64)), np.max(np.abs(ref - ref64) / np.abs(ref64))))
