@@ -34,7 +34,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMaxNT = 3;       // tiles (of 32 frames) a wave carries through one pass over the taps
-constexpr int kWavesPerCU = 20; // five per SIMD (measured: 12: 483 us, 20: 451, 28: 445 on config 2)
+constexpr int kWavesPerCU = 28; // seven per SIMD, what 68 registers allow (measured on config 2: 12: 480 us, 20: 452, 28: 441)
 
 // One wave per 64 frames (two blocks).  Lane l = 16 c + i reads row 32 (2 w + (c >> 1)) + 2 i + (c & 1), so that the
 // ballot of feature k is four 16-bit fields (block half, parity) and lane c < 4 assembles word c from the four
