@@ -5,6 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no launcher environment starts its own N rank processes
+(launch_ranks below: the parent never loads the HIP library or touches a GPU, nothing is re-exec'ed;
+it relays rank 0's JSON line and exits with the worst child status).  Under torch.distributed.run the
+ranks are the launcher's.
+
 Workload (BASELINE.json configs[1], SURVEY.md section 8(d) "config 2"), per GPU:
 1 000 synthetic utterances x 200 frames of binary edge features (45 x 8 = 360
 per frame), scored against an 8-template bank (L = 32): one LAUNCH of the
@@ -33,6 +38,66 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "template-speech-recognition_amd"))
+
+
+def _wanted_gpus(argv):
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+def launch_ranks(n, argv):
+    """Parent of a self-launched N-GPU run: one child process per GPU with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set (what torch.distributed.run would export), the same argv, a fresh shared
+    secret for the host control plane.  This process imports neither tsr_hip nor torch and makes no GPU call.
+    Rank 0's stdout is relayed line by line; the others' stdout goes to stderr.  If a rank fails, the rest get
+    20 s to notice (they leave through the control plane's own errors) and are then terminated by PID."""
+    import secrets
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               TORCHELASTIC_RUN_ID="bench%d_%d" % (os.getpid(), int(time.time())), TSR_CTRL_SECRET=secrets.token_hex(32),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("TSR_CTRL_PORT", None)
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    try:
+        for line in procs[0].stdout:      # rank 0 prints the one JSON line
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        failed_at = None
+        while any(p.poll() is None for p in procs):
+            if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+                failed_at = time.time()
+            if failed_at is not None and time.time() - failed_at > 20.0:
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    codes = [p.returncode for p in procs]
+    worst = max((c for c in codes), key=lambda c: (c != 0, abs(c)))
+    return worst if worst >= 0 else 128 - worst
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _wanted_gpus(sys.argv[1:]) > 1:
+    raise SystemExit(launch_ranks(_wanted_gpus(sys.argv[1:]), sys.argv[1:]))   # before anything loads HIP
 
 import tsr_hip  # noqa: E402  (loads libtsr_hip.so before anything else touches HIP)
 from tsr_hip import dist as tdist  # noqa: E402
@@ -253,6 +318,22 @@ def stored_traffic(mode):
     return None, {"source": None, "measured_in_this_run": False}
 
 
+def dry_run_ranks(world, rank):
+    """The host side of an N-rank run with the GPU work left out (tests/test_bench_launch_cpu.py)."""
+    group = tdist.HostGroup.from_env(timeout=60) if world > 1 else tdist.HostGroup(0, 1)
+    uid = tdist.exchange_unique_id(group, lambda: bytes(range(128)))
+    bank = tdist.broadcast_object(group, synth.corpus(2, N=2, T=40, F=5, E=4, M=2, L=8)["bank"] if rank == 0 else None)
+    group.barrier()
+    wall, = tdist.max_over_ranks(group, 0.001 * (rank + 1))
+    ranks = tdist._allgather(group, [rank, int(os.environ.get("LOCAL_RANK", "-1")), os.getpid()])
+    if rank == 0:
+        print(json.dumps({"metric": "scored frames/sec (whole node) + achieved HBM GB/s vs roofline", "dry_run": True,
+                          "n_gpus": world, "value": None, "max_over_ranks_s": wall, "ranks": ranks,
+                          "bank_templates": len(bank), "uid_ok": uid == bytes(range(128))}))
+    group.barrier()
+    group.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -273,15 +354,18 @@ def main():
     ap.add_argument("--extras", action="store_true",
                     help="N=1 only: add the PCIe-inclusive rate and BASELINE config 3 (parts front-end + "
                          "D=2050 bank) to the JSON line under \"extras\" (never part of `value`)")
+    ap.add_argument("--dry-run-ranks", action="store_true",
+                    help="(CPU test of the launcher) every rank runs the N > 1 host control flow -- rendezvous, id "
+                         "hand-over, bank over the host channel, barriers, max over ranks -- without a GPU call")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N")
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.dry_run_ranks:
+        return dry_run_ranks(world, rank)
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this driver)
     allcores = cpu_allcores() if (args.extras and world == 1) else None   # forks: before any GPU call

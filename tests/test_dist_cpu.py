@@ -81,7 +81,7 @@ def _worker_sockets(rank, world, port, out, via_env):
             os.environ.pop("TSR_CTRL_PORT", None)
             g = tdist.HostGroup.from_env(timeout=60)
         else:
-            g = tdist.HostGroup(rank, world, "127.0.0.1", port, timeout=60)
+            g = tdist.HostGroup(rank, world, "127.0.0.1", port, timeout=60, secret=b"pytest-secret-%d" % port)
         try:
             _exercise(g, rank, world)
             out.put((rank, "ok"))
@@ -118,6 +118,81 @@ def test_host_group_world_size_1_is_local():
     assert g.allgather(5) == [5] and tdist.max_over_ranks(g, 1.5, 2.0) == [1.5, 2.0]
     g.barrier()
     g.close()
+
+
+def test_wire_encoding_is_closed_and_round_trips():
+    obj = {"a": [1, 2.5, None, True, "x", b"\x00\x01"], "t": (np.arange(6, dtype=np.float32).reshape(2, 3), 3),
+           "bank": ((np.ones((2, 3), np.float32), 1.5),)}
+    back = tdist.decode(tdist.encode(obj))
+    assert back["a"] == obj["a"] and isinstance(back["t"], tuple) and back["t"][1] == 3
+    assert np.array_equal(back["t"][0], obj["t"][0]) and back["t"][0].dtype == np.float32
+    assert np.array_equal(back["bank"][0][0], obj["bank"][0][0]) and back["bank"][0][1] == 1.5
+    import pickle
+    import pytest
+    with pytest.raises(TypeError):
+        tdist.encode(object())                       # nothing outside the closed set is sent
+    with pytest.raises(TypeError):
+        tdist.encode(np.array([object()], dtype=object))
+    with pytest.raises(ValueError):
+        tdist.decode(pickle.dumps({"x": 1}))         # ... and a pickle is not a message
+    with pytest.raises(ValueError):
+        tdist.decode(tdist.encode([1, 2]) + b"N")
+
+
+def test_control_plane_is_loopback_only_and_needs_a_secret():
+    import pytest
+    with pytest.raises(ValueError, match="loopback"):
+        tdist.HostGroup(0, 2, "10.1.2.3", 0, secret=b"s")
+    with pytest.raises(ValueError, match="loopback"):
+        tdist.HostGroup(1, 2, "example.org", 1234, secret=b"s")
+    with pytest.raises(ValueError, match="secret"):
+        tdist.HostGroup(0, 2, "127.0.0.1", 0)
+
+
+def _worker_hostile(rank, world, port, out):
+    """Rank 0 must survive stray / short / silent / unauthenticated connections made before rank 1 arrives."""
+    import struct
+    import time
+    try:
+        secret = b"right-secret"
+        if rank == 1:
+            time.sleep(0.3)
+            s1 = socket.create_connection(("127.0.0.1", port))    # silent: never sends a byte
+            s2 = socket.create_connection(("127.0.0.1", port))    # short: closes mid-handshake
+            s2.sendall(b"TSR")
+            s2.close()
+            s3 = socket.create_connection(("127.0.0.1", port))    # right magic and rank, wrong secret
+            s3.sendall(b"TSRCTRL2" + struct.pack("<ii", 1, 2) + b"n" * 16)
+            s3.recv(48)
+            s3.sendall(b"x" * 32)
+            try:
+                bad = tdist.HostGroup(1, 2, "127.0.0.1", port, timeout=3, secret=b"wrong-secret")
+                bad.close()
+                out.put((rank, "a wrong secret was admitted"))
+                return
+            except RuntimeError:
+                pass
+            s1.close()
+            s3.close()
+        g = tdist.HostGroup(rank, world, "127.0.0.1", port, timeout=60, secret=secret)
+        try:
+            assert g.allgather(rank) == [0, 1]
+            out.put((rank, "ok"))
+        finally:
+            g.close()
+    except Exception as e:  # pragma: no cover
+        out.put((rank, repr(e)))
+
+
+def test_rank0_survives_stray_and_unauthenticated_connections():
+    assert _run(_worker_hostile, 2) == {0: "ok", 1: "ok"}
+
+
+def test_rendezvous_file_is_private():
+    import stat
+    d = tdist._private_dir()
+    st = os.lstat(d)
+    assert stat.S_ISDIR(st.st_mode) and not (st.st_mode & 0o077) and st.st_uid == os.getuid()
 
 
 def test_product_package_does_not_import_torch():
