@@ -93,6 +93,25 @@ int tsr_ctx_sync(tsr_ctx *ctx);
 /* hipEvent pair on the ctx stream: kernel time of everything enqueued between. */
 int tsr_timer_start(tsr_ctx *ctx);
 int tsr_timer_stop(tsr_ctx *ctx, float *elapsed_ms);
+/* Kernel-choice options of a context.  Which kernel produces a result never depends on the
+ * process environment after the context exists: the defaults are read from the environment ONCE,
+ * inside tsr_ctx_create (TSR_FASTK = tap2|old, TSR_EXACTK = valu|mfma, TSR_PART_LAYOUT = bytes|bits,
+ * TSR_XCD_MAP = 0|1 -- diagnostics), and from then on only tsr_ctx_set_option
+ * changes them.  Every choice yields the same results (bit for bit within TSR_EXACT, within
+ * TSR_FAST's exact integer sums, and for the part features); the options exist for A/B timing.
+ *   TSR_OPT_FAST_KERNEL   two-limb TSR_FAST kernel: AUTO (tap-pair kernel on narrow rows, else the
+ *                         interleaved one), TSR_FAST_KERNEL_TAP2 (wherever it fits), TSR_FAST_KERNEL_INTERLEAVED
+ *   TSR_OPT_EXACT_KERNEL  TSR_EXACT: AUTO (matrix cores where the bank has that form), TSR_EXACT_KERNEL_VALU
+ *   TSR_OPT_PART_LAYOUT   what tsr_corpus_part_features leaves resident: AUTO (bit rows when the
+ *                         dilation kernel can write them, K <= 64), TSR_PART_LAYOUT_BYTES, TSR_PART_LAYOUT_BITS
+ *   TSR_OPT_XCD_MAP       XCD-aware placement of multi-group bank passes: 1 (default) / 0 */
+enum { TSR_OPT_FAST_KERNEL = 1, TSR_OPT_EXACT_KERNEL = 2, TSR_OPT_PART_LAYOUT = 3, TSR_OPT_XCD_MAP = 4 };
+enum { TSR_OPT_AUTO = 0,
+       TSR_FAST_KERNEL_TAP2 = 1, TSR_FAST_KERNEL_INTERLEAVED = 2,
+       TSR_EXACT_KERNEL_VALU = 1, TSR_EXACT_KERNEL_MFMA = 2,
+       TSR_PART_LAYOUT_BYTES = 1, TSR_PART_LAYOUT_BITS = 2 };
+int tsr_ctx_set_option(tsr_ctx *ctx, int option, int value);
+int tsr_ctx_get_option(const tsr_ctx *ctx, int option, int *value);
 /* device name, CU count, HBM bytes (for bench/DESIGN reporting) */
 int tsr_device_info(tsr_ctx *ctx, char *name, int name_len, int *cus, int64_t *hbm_bytes);
 
@@ -207,6 +226,11 @@ int tsr_parts_info(const tsr_parts *parts, int *mfma_available, int64_t *locatio
 /* Read back a corpus: feature bytes u8 [sum T_n, D]; its shape (frame_offsets i64 [N+1], may be NULL). */
 int tsr_corpus_download_feats(tsr_ctx *ctx, const tsr_corpus *corpus, uint8_t *feats);
 int tsr_corpus_shape(const tsr_corpus *corpus, int64_t *N, int64_t *D, int64_t *frame_offsets);
+/* What a corpus keeps resident: *layout bit 0 = byte rows [sum T, round_up(D,16)] in {0,1}, bit 1 = bit rows
+ * [sum T, round_up(ceil(D/8),16)] (bit d of a row = feature d; what tsr_corpus_part_features writes when it can:
+ * an eighth of the bytes, read as they are by the two-limb TSR_FAST pass on wide rows; byte rows are derived from
+ * them on first use by anything else and then kept); *feature_bytes = device bytes of those forms.  Pointers may be NULL. */
+int tsr_corpus_layout(const tsr_corpus *corpus, int *layout, int64_t *feature_bytes);
 
 /* ---- phone-window classification on top of the scores ----------- */
 /* _compute_classification_E (get_train_data.py:718-773) over a resident corpus.  Window w is the

@@ -225,6 +225,7 @@ static int ensure_planes(tsr_ctx *ctx, tsr_corpus *cp, int Lmax)
         cp->d_planes = nullptr;
     }
     const int64_t nb2 = nb + 8;  // (a little headroom for the next, slightly longer bank)
+    TSR_TRY(tsr_corpus_need_bytes(ctx, cp));  // (the planes are ballots of the byte rows)
     const int NK = cp->Dp / 4;
     TSR_HIP(hipMalloc(reinterpret_cast<void **>(&cp->d_planes), (size_t)2 * nb2 * NK * 8));
     cp->planes_nb = nb2;
@@ -246,7 +247,6 @@ int tsr_launch_exact_bank_mfma(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *c
     const bool pairs = bank->n_groups > 1;
     const int64_t U = nTiles * (pairs ? (bank->n_groups + 1) / 2 : 1);
     int wpc = pairs ? 16 : kWavesPerCU;  // (the pair form fits four waves per SIMD)
-    if (const char *e = getenv("TSR_EXACT_WPC")) wpc = std::max(1, atoi(e));  // (experiments)
     const int64_t slots = (int64_t)wpc * ctx->cus;
     // as many waves as the chip is to hold, but none with less than one tile
     const int64_t nW = std::max<int64_t>(1, std::min<int64_t>(slots, U));

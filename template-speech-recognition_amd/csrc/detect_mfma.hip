@@ -8,6 +8,10 @@ namespace tsr_fast {
 TSR_FAST_EXTERN(1) TSR_FAST_EXTERN(2) TSR_FAST_EXTERN(3) TSR_FAST_EXTERN(4) TSR_FAST_EXTERN(5) TSR_FAST_EXTERN(6)
 TSR_FAST_EXTERN(7) TSR_FAST_EXTERN(8) TSR_FAST_EXTERN(9) TSR_FAST_EXTERN(10) TSR_FAST_EXTERN(11) TSR_FAST_EXTERN(12)
 #undef TSR_FAST_EXTERN
+#define TSR_BITS_EXTERN(N) extern template int launch_bits<N>(tsr_ctx *, const FastArgs &, int, size_t);
+TSR_BITS_EXTERN(1) TSR_BITS_EXTERN(2) TSR_BITS_EXTERN(3) TSR_BITS_EXTERN(4) TSR_BITS_EXTERN(5) TSR_BITS_EXTERN(6)
+TSR_BITS_EXTERN(7) TSR_BITS_EXTERN(8) TSR_BITS_EXTERN(9) TSR_BITS_EXTERN(10) TSR_BITS_EXTERN(11) TSR_BITS_EXTERN(12)
+#undef TSR_BITS_EXTERN
 }  // namespace tsr_fast
 
 namespace tsr_fast {
@@ -454,6 +458,7 @@ int tsr_launch_tap2_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, flo
 {
     const FastBank *fb = static_cast<const FastBank *>(bank->fast[4]);
     if (!fb) return TSR_ERR_UNSUPPORTED;
+    TSR_TRY(tsr_corpus_need_bytes(ctx, cp));  // (this kernel stages byte rows)
     const int64_t P = cp->P;
     if (P == 0) return TSR_OK;
     const int Dp = cp->Dp;
@@ -477,10 +482,8 @@ int tsr_launch_tap2_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, flo
     nseg = (int)std::max<int64_t>(1, std::min<int64_t>(nseg, (P + min_rows - 1) / min_rows));
     int spx = 0;
     if (fb->G > 1 && fb->G <= ctx->cus / 8) {  // (one workgroup per CU: 256 registers per wave)
-        const char *e = getenv("TSR_XCD_MAP");
-        int want = (ctx->cus / 8) / fb->G;
-        if (const char *m = getenv("TSR_TAP2_SPXMUL")) want *= std::max(1, atoi(m));  // (experiments)
-        if (!(e && e[0] == '0') && want >= 1 && (int64_t)8 * want * min_rows * 2 <= P) {
+        const int want = (ctx->cus / 8) / fb->G;
+        if (ctx->opt_xcd_map && want >= 1 && (int64_t)8 * want * min_rows * 2 <= P) {
             spx = want;
             nseg = 8 * spx;
         }
@@ -534,6 +537,10 @@ int tsr_launch_tap2_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, flo
         a.scores = d_scores;
         a.ids = d_ids;
         a.all = d_all;
+    }
+    {  // (tsr_internal.h: tsr_staging_read_end; the tap-pair kernel stages flat tiles of exactly 32 rows)
+        const size_t end = tsr_staging_read_end(P, Dp, Dp, Dp >> 4, 32 * Dp, true, 0);
+        TSR_REQUIRE(end <= cp->feats_alloc, "TSR_FAST: frame staging would read %zu bytes of a %zu-byte feature array", end, cp->feats_alloc);
     }
     int s;
     switch (fb->NKB) {
@@ -592,13 +599,17 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
     if (!fb) return TSR_ERR_UNSUPPORTED;
     const int64_t P = cp->P;
     if (P == 0) return TSR_OK;
+    // A corpus resident as bit rows (a part corpus) is read as such by the two-limb interleaved kernel (one K-slice per
+    // workgroup); every other kernel reads byte rows, made from the bits on first use.
+    const bool bits = cp->d_bits != nullptr && !bf && NL == 2 && fb->KS == 1;
+    if (!bits) TSR_TRY(tsr_corpus_need_bytes(ctx, cp));
     if (bf) TSR_TRY(tsr_corpus_bf16_copy(ctx, cp));
     // (bf16: the "row" is the bf16 copy's, its stride already an odd number of 16-byte slots)
     const int Dp = bf ? cp->bf16_stride : cp->Dp;
     // LDS row: the bytes one pass needs of a frame (the whole resident row, or one K-phase of
     // it), as an odd number of 16-byte slots so that b128 fragment reads are conflict-free
     const int k_span = fb->KS * fb->NKB * 32;  // bytes of a row one pass reads (int8: 32 features per K-block; bf16: 16)
-    int row_bytes = fb->n_phase == 1 ? Dp : k_span;  // source bytes copied per frame and pass
+    int row_bytes = (fb->n_phase == 1 && !bits) ? Dp : k_span;  // source bytes copied per frame and pass (bit rows: expanded)
     int SB = row_bytes;
     if (((SB >> 4) & 1) == 0) SB += 16;
     // a tile buffer: 32 rows, rounded up to whole 1 KiB DMA pieces, plus the bytes the last
@@ -628,9 +639,8 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
     // keep >= 98 % of the slots busy for G <= 9 where one round would leave up to G - 1 of 32 idle.
     int spx = 0;
     if (fb->G > 1 && fb->G <= 2 * (ctx->cus / 8)) {
-        const char *e = getenv("TSR_XCD_MAP");
         const int want = (2 * (ctx->cus / 8)) / fb->G;
-        if (!(e && e[0] == '0') && want >= 1 && (int64_t)8 * want * min_rows * 4 <= P) {
+        if (ctx->opt_xcd_map && want >= 1 && (int64_t)8 * want * min_rows * 4 <= P) {
             spx = want;
             nseg = 8 * spx;
         }
@@ -641,7 +651,7 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
     void *raw_frag = nullptr;
     if (fragments) TSR_TRY(tsr_scratch(ctx, 0, (size_t)fb->n_frag * P * sizeof(float), &raw_frag));
     const int grid = nseg * fb->G;
-    const bool flat = (SB == Dp) && fb->n_phase == 1;
+    const bool flat = (SB == Dp) && fb->n_phase == 1 && !bits;
     unsigned long long *d_dbg = nullptr;
 #ifdef TSR_STAMP
     TSR_HIP(hipMalloc(reinterpret_cast<void **>(&d_dbg), (size_t)grid * kWaves * 6 * 8));
@@ -654,6 +664,12 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
         a.Dp = Dp;
         a.SB = SB;
         a.src_slots = row_bytes >> 4;
+        if (bits) {  // bit rows: the phase's features are dwords [ph * k_span / 32, +NKB) of a row of Bp bytes
+            a.X = cp->d_bits;
+            a.Dp = cp->Bp;
+            a.src_slots = cp->Bp >> 2;
+            a.bit_dword0 = ph * (k_span >> 5);
+        }
         a.tile_bytes = tile_bytes;
         a.G = fb->G;
         a.CT = fb->CT;
@@ -679,6 +695,14 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
             a.ids = d_ids;
             a.all = d_all;
         }
+        if (bits) {  // whole bit rows of the tiles' 32 frames: the last tile starts at a frame of the corpus
+            TSR_REQUIRE((size_t)(P + 31) * (size_t)cp->Bp <= cp->bits_alloc, "TSR_FAST: frame staging would read past the %zu-byte bit rows", cp->bits_alloc);
+        } else {  // the staging's read-ahead stays inside the array it reads (tsr_internal.h: tsr_staging_read_end)
+            const size_t end = tsr_staging_read_end(P, Dp, SB, a.src_slots, tile_bytes, flat, bf ? 0 : (size_t)ph * k_span);
+            const size_t have = bf ? cp->bf16_alloc : cp->feats_alloc;
+            TSR_REQUIRE(end <= have, "TSR_FAST: frame staging would read %zu bytes of a %zu-byte %s array (P=%lld, row %d, tile %d)",
+                        end, have, bf ? "bf16" : "feature", (long long)P, Dp, tile_bytes);
+        }
         int s;
         if (bf) {
             // the kernel is instantiated for exactly this geometry: refuse anything else rather than launch
@@ -687,6 +711,24 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
                 return TSR_ERR_UNSUPPORTED;
             }
             TSR_TRY(launch_bf16(ctx, a, grid, lds, NL));
+            continue;
+        }
+        if (bits) {
+            switch (fb->NKB) {
+            case 1: s = launch_bits<1>(ctx, a, grid, lds); break;
+            case 2: s = launch_bits<2>(ctx, a, grid, lds); break;
+            case 3: s = launch_bits<3>(ctx, a, grid, lds); break;
+            case 4: s = launch_bits<4>(ctx, a, grid, lds); break;
+            case 5: s = launch_bits<5>(ctx, a, grid, lds); break;
+            case 6: s = launch_bits<6>(ctx, a, grid, lds); break;
+            case 7: s = launch_bits<7>(ctx, a, grid, lds); break;
+            case 8: s = launch_bits<8>(ctx, a, grid, lds); break;
+            case 9: s = launch_bits<9>(ctx, a, grid, lds); break;
+            case 10: s = launch_bits<10>(ctx, a, grid, lds); break;
+            case 11: s = launch_bits<11>(ctx, a, grid, lds); break;
+            default: s = launch_bits<12>(ctx, a, grid, lds); break;
+            }
+            TSR_TRY(s);
             continue;
         }
         switch (fb->NKB) {

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void corpus_to_bf16_kernel(const uint8_t *__re
 int tsr_corpus_bf16_copy(tsr_ctx *ctx, tsr_corpus *cp)
 {
     if (cp->d_feats_bf16) return TSR_OK;
+    TSR_TRY(tsr_corpus_need_bytes(ctx, cp));
     int stride = 2 * cp->Dp;
     if (((stride >> 4) & 1) == 0) stride += 16;  // odd number of 16-byte slots: conflict-free fragment reads
     const size_t body = (size_t)cp->P * stride, slack = (size_t)48 * stride + 8192;
@@ -53,5 +54,6 @@ int tsr_corpus_bf16_copy(tsr_ctx *ctx, tsr_corpus *cp)
         TSR_HIP(hipGetLastError());
     }
     cp->bf16_stride = stride;
+    cp->bf16_alloc = body + slack;
     return TSR_OK;
 }

@@ -4,4 +4,6 @@
 namespace tsr_fast {
 template int launch<1>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
 template int launch<2>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
+template int launch_bits<1>(tsr_ctx *, const FastArgs &, int, size_t);
+template int launch_bits<2>(tsr_ctx *, const FastArgs &, int, size_t);
 }  // namespace tsr_fast

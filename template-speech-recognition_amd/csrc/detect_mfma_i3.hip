@@ -4,4 +4,6 @@
 namespace tsr_fast {
 template int launch<7>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
 template int launch<8>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
+template int launch_bits<7>(tsr_ctx *, const FastArgs &, int, size_t);
+template int launch_bits<8>(tsr_ctx *, const FastArgs &, int, size_t);
 }  // namespace tsr_fast

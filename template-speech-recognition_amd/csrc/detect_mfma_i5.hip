@@ -4,4 +4,6 @@
 namespace tsr_fast {
 template int launch<11>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
 template int launch<12>(tsr_ctx *, const FastArgs &, int, size_t, int, bool);
+template int launch_bits<11>(tsr_ctx *, const FastArgs &, int, size_t);
+template int launch_bits<12>(tsr_ctx *, const FastArgs &, int, size_t);
 }  // namespace tsr_fast

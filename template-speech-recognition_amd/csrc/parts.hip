@@ -308,11 +308,10 @@ __global__ __launch_bounds__(64 * kSpreadWaves) void spread_mask_multi_kernel(
     const int32_t *__restrict__ A, int N1, int r0, int r1, int K, int g1, int O1, int64_t P_out,
     const int32_t *__restrict__ out_src_row, const int32_t *__restrict__ out_src_lo,
     const int32_t *__restrict__ out_src_hi, const uint64_t *__restrict__ graph_masks /*[K] or null*/, int Dp_out,
-    uint8_t *__restrict__ out)
+    uint8_t *__restrict__ out, uint8_t *__restrict__ out_bits /* bit rows instead of byte rows */, int Bp, int nwords)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sp_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nwords = (Dp_out >> 5) + 3;
     const size_t per_wave = ((size_t)kSpreadRows * N1 * 8 + (size_t)kSpreadFB * nwords * 4 + 7) / 8 * 8;
     uint64_t *bits = reinterpret_cast<uint64_t *>(sp_smem + (size_t)wave * per_wave);  // [kSpreadRows][N1]
     uint32_t *streams = reinterpret_cast<uint32_t *>(bits + (size_t)kSpreadRows * N1);  // [FB][nwords]
@@ -401,6 +400,15 @@ __global__ __launch_bounds__(64 * kSpreadWaves) void spread_mask_multi_kernel(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- bit rows: the streams as they stand (bit oj*K + k of a frame = its feature oj*K + k), whole rows ----
+        if (out_bits) {
+            for (int f = f_beg; f < f_end; ++f) {
+                uint32_t *row = reinterpret_cast<uint32_t *>(out_bits + (q0 + f) * Bp);
+                for (int w = lane; w < (Bp >> 2); w += 64) row[w] = streams[f * nwords + w];
+            }
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
         // ---- expand the streams to bytes: whole 16-byte chunks of the frames' rows ----------------------
         for (int f = f_beg; f < f_end; ++f) {
             uint8_t *row = out + (q0 + f) * Dp_out;
@@ -454,22 +462,40 @@ int tsr_launch_out_geometry(tsr_ctx *ctx, const int64_t *d_ooff, const int32_t *
 
 // `d_out` rows need no zeroing when this returns with *wrote_all = true (mask kernel); the
 // byte-scatter kernel (K > 64) needs them zeroed and does that itself.
+static int spread_multi_words(int Dp_out, int Bp) { return std::max((Dp_out >> 5) + 3, Bp >> 2); }
+static size_t spread_multi_lds(int64_t N1, int Dp_out, int Bp)
+{
+    return (size_t)kSpreadWaves * (((size_t)kSpreadRows * N1 * 8 + (size_t)kSpreadFB * spread_multi_words(Dp_out, Bp) * 4 + 7) / 8 * 8);
+}
+
+// Can the dilation write the part features as bit rows (tsr_corpus.d_bits)?  Only the mask kernel that handles several
+// frames per wave does: at most 64 parts, dilation window of at most kSpreadRows source rows, its strips within 64 KB.
+bool tsr_spread_packs_bits(int64_t N1, int r0, int64_t K, int Dp_out, int Bp)
+{
+    return K <= 64 && 2 * r0 + 1 <= kSpreadRows && spread_multi_lds(N1, Dp_out, Bp) <= 64 * 1024 && Dp_out % 16 == 0 && Bp % 16 == 0;
+}
+
 int tsr_launch_spread_stream(tsr_ctx *ctx, const int32_t *d_A, int64_t N1, int r0, int r1, int64_t K,
                              int g0, int g1, int64_t O1, int64_t P_out, const int32_t *d_src_row,
                              const int32_t *d_src_lo, const int32_t *d_src_hi, const uint8_t *d_graph,
-                             const uint64_t *d_graph_masks, int Dp_out, uint8_t *d_out)
+                             const uint64_t *d_graph_masks, int Dp_out, uint8_t *d_out, uint8_t *d_out_bits, int Bp)
 {
     (void)g0;
     const int64_t n = P_out * O1;
     if (n <= 0) return TSR_OK;
+    if (d_out_bits && !tsr_spread_packs_bits(N1, r0, K, Dp_out, Bp)) {
+        tsr_set_error("spread: bit rows asked for a geometry the mask kernel does not cover");
+        return TSR_ERR_UNSUPPORTED;
+    }
     const size_t per_wave = ((size_t)(2 * r0 + 1) * N1 * 8 + ((size_t)(Dp_out >> 5) + 3) * 4 + 7) / 8 * 8;
     const size_t lds = (size_t)kSpreadWaves * per_wave;
-    const size_t per_wave_m = ((size_t)kSpreadRows * N1 * 8 + (size_t)kSpreadFB * ((size_t)(Dp_out >> 5) + 3) * 4 + 7) / 8 * 8;
-    if (K <= 64 && 2 * r0 + 1 <= kSpreadRows && kSpreadWaves * per_wave_m <= 64 * 1024 && Dp_out % 16 == 0) {
+    const int bp_eff = d_out_bits ? Bp : 0;
+    if (K <= 64 && 2 * r0 + 1 <= kSpreadRows && spread_multi_lds(N1, Dp_out, bp_eff) <= 64 * 1024 && Dp_out % 16 == 0) {
         const int64_t frames_per_block = (int64_t)kSpreadWaves * kSpreadFB;
         hipLaunchKernelGGL(spread_mask_multi_kernel, dim3((unsigned)((P_out + frames_per_block - 1) / frames_per_block)),
-                           dim3(64 * kSpreadWaves), kSpreadWaves * per_wave_m, ctx->stream, d_A, (int)N1, r0, r1, (int)K, g1,
-                           (int)O1, P_out, d_src_row, d_src_lo, d_src_hi, d_graph ? d_graph_masks : nullptr, Dp_out, d_out);
+                           dim3(64 * kSpreadWaves), spread_multi_lds(N1, Dp_out, bp_eff), ctx->stream, d_A, (int)N1, r0, r1, (int)K, g1,
+                           (int)O1, P_out, d_src_row, d_src_lo, d_src_hi, d_graph ? d_graph_masks : nullptr, Dp_out, d_out,
+                           d_out_bits, Bp, spread_multi_words(Dp_out, bp_eff));
         TSR_HIP(hipGetLastError());
         return TSR_OK;
     }

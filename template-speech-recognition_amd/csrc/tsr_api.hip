@@ -89,8 +89,54 @@ TSR_API int tsr_ctx_create(int device, tsr_ctx **out)
         tsr_ctx_destroy(ctx);  // frees whatever was created
         return TSR_ERR_HIP;
     }
+    // option defaults: the environment is consulted here and nowhere else
+    if (const char *e = getenv("TSR_FASTK")) ctx->opt_fast_kernel = e[0] == 't' ? TSR_FAST_KERNEL_TAP2 : (e[0] == 'o' ? TSR_FAST_KERNEL_INTERLEAVED : TSR_OPT_AUTO);
+    if (const char *e = getenv("TSR_EXACTK")) ctx->opt_exact_kernel = e[0] == 'v' ? TSR_EXACT_KERNEL_VALU : (e[0] == 'm' ? TSR_EXACT_KERNEL_MFMA : TSR_OPT_AUTO);
+    if (const char *e = getenv("TSR_PART_LAYOUT")) ctx->opt_part_layout = !strcmp(e, "bytes") ? TSR_PART_LAYOUT_BYTES : (!strcmp(e, "bits") ? TSR_PART_LAYOUT_BITS : TSR_OPT_AUTO);
+    if (const char *e = getenv("TSR_XCD_MAP")) ctx->opt_xcd_map = e[0] != '0';
     *out = ctx;
     return TSR_OK;
+}
+
+TSR_API int tsr_ctx_set_option(tsr_ctx *ctx, int option, int value)
+{
+    TSR_REQUIRE(ctx, "tsr_ctx_set_option: null ctx");
+    switch (option) {
+    case TSR_OPT_FAST_KERNEL:
+        TSR_REQUIRE(value >= 0 && value <= TSR_FAST_KERNEL_INTERLEAVED, "tsr_ctx_set_option: bad value %d for TSR_OPT_FAST_KERNEL", value);
+        ctx->opt_fast_kernel = value;
+        return TSR_OK;
+    case TSR_OPT_EXACT_KERNEL:
+        TSR_REQUIRE(value >= 0 && value <= TSR_EXACT_KERNEL_MFMA, "tsr_ctx_set_option: bad value %d for TSR_OPT_EXACT_KERNEL", value);
+        ctx->opt_exact_kernel = value;
+        return TSR_OK;
+    case TSR_OPT_PART_LAYOUT:
+        TSR_REQUIRE(value >= 0 && value <= TSR_PART_LAYOUT_BITS, "tsr_ctx_set_option: bad value %d for TSR_OPT_PART_LAYOUT", value);
+        ctx->opt_part_layout = value;
+        return TSR_OK;
+    case TSR_OPT_XCD_MAP:
+        TSR_REQUIRE(value == 0 || value == 1, "tsr_ctx_set_option: bad value %d for TSR_OPT_XCD_MAP", value);
+        ctx->opt_xcd_map = value;
+        return TSR_OK;
+    default:
+        break;
+    }
+    tsr_set_error("tsr_ctx_set_option: unknown option %d", option);
+    return TSR_ERR_INVALID;
+}
+
+TSR_API int tsr_ctx_get_option(const tsr_ctx *ctx, int option, int *value)
+{
+    TSR_REQUIRE(ctx && value, "tsr_ctx_get_option: null pointer");
+    switch (option) {
+    case TSR_OPT_FAST_KERNEL: *value = ctx->opt_fast_kernel; return TSR_OK;
+    case TSR_OPT_EXACT_KERNEL: *value = ctx->opt_exact_kernel; return TSR_OK;
+    case TSR_OPT_PART_LAYOUT: *value = ctx->opt_part_layout; return TSR_OK;
+    case TSR_OPT_XCD_MAP: *value = ctx->opt_xcd_map; return TSR_OK;
+    default: break;
+    }
+    tsr_set_error("tsr_ctx_get_option: unknown option %d", option);
+    return TSR_ERR_INVALID;
 }
 
 TSR_API int tsr_ctx_destroy(tsr_ctx *ctx)
@@ -398,10 +444,71 @@ TSR_API int tsr_bank_info(const tsr_bank *b, int32_t *M, int64_t *D, int32_t *Lm
 // ---- corpus ---------------------------------------------------------------------
 TSR_API int tsr_corpus_destroy(tsr_corpus *cp);
 
+// Byte rows of a corpus: [P][Dp] + zeroed slack behind the last row (tiles of the scoring kernels may read, never use,
+// up to tile_bytes - Dp bytes past it: tsr_staging_read_end).
+static int corpus_alloc_bytes(tsr_ctx *ctx, tsr_corpus *cp)
+{
+    const size_t body = (size_t)cp->P * cp->Dp, slack = (size_t)48 * cp->Dp + 8192;
+    if (hipMalloc(reinterpret_cast<void **>(&cp->d_feats), body + slack) != hipSuccess ||
+        hipMemsetAsync(cp->d_feats + body, 0, slack, ctx->stream) != hipSuccess) {
+        tsr_set_error("tsr_corpus_create: cannot allocate %zu bytes of device memory", body + slack);
+        return TSR_ERR_HIP;
+    }
+    cp->feats_alloc = body + slack;
+    return TSR_OK;
+}
+
+int tsr_corpus_alloc_bits(tsr_ctx *ctx, tsr_corpus *cp)
+{
+    cp->Bp = (int)(((cp->D + 7) / 8 + 15) / 16 * 16);
+    const size_t body = (size_t)cp->P * cp->Bp, slack = (size_t)48 * cp->Bp + 8192;
+    if (hipMalloc(reinterpret_cast<void **>(&cp->d_bits), body + slack) != hipSuccess ||
+        hipMemsetAsync(cp->d_bits + body, 0, slack, ctx->stream) != hipSuccess) {
+        tsr_set_error("tsr_corpus_part_features: cannot allocate %zu bytes of device memory", body + slack);
+        return TSR_ERR_HIP;
+    }
+    cp->bits_alloc = body + slack;
+    return TSR_OK;
+}
+
+namespace {
+// bit rows [P][Bp] -> byte rows [P][Dp] in {0,1}; one lane per 16 output bytes, bytes past D are zero
+__global__ __launch_bounds__(256) void corpus_unpack_bits_kernel(const uint8_t *__restrict__ bits, int64_t P, int Bp, int D, int Dp,
+                                                                 uint8_t *__restrict__ out)
+{
+    const int per_row = Dp >> 4;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P * per_row) return;
+    const int64_t p = i / per_row;
+    const int c = (int)(i - p * per_row);
+    unsigned b = reinterpret_cast<const uint16_t *>(bits + p * Bp)[c];
+    const int left = D - 16 * c;  // features of this chunk that exist
+    if (left < 16) b &= (1u << (left > 0 ? left : 0)) - 1u;
+    unsigned w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = (((b >> (4 * q)) & 0xfu) * 0x00204081u) & 0x01010101u;
+    *reinterpret_cast<uint4 *>(out + p * Dp + 16 * c) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+}  // namespace
+
+int tsr_corpus_need_bytes(tsr_ctx *ctx, const tsr_corpus *cpc)
+{
+    tsr_corpus *cp = const_cast<tsr_corpus *>(cpc);  // a derived form, cached (corpora are immutable once created)
+    if (cp->d_feats || cp->P == 0) return TSR_OK;
+    TSR_REQUIRE(cp->d_bits, "corpus holds no features");
+    TSR_HIP(hipSetDevice(ctx->device));
+    TSR_TRY(corpus_alloc_bytes(ctx, cp));
+    const int64_t n = cp->P * (cp->Dp >> 4);
+    hipLaunchKernelGGL(corpus_unpack_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, cp->d_bits, cp->P,
+                       cp->Bp, (int)cp->D, cp->Dp, cp->d_feats);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+
 // Allocate a corpus (resident feature rows zero-initialised only in the slack, utterance tables
 // uploaded, result arrays allocated) without any feature data.
 int tsr_corpus_create_empty(tsr_ctx *ctx, const int64_t *frame_offsets, int64_t N, int64_t D,
-                            tsr_corpus **out)
+                            tsr_corpus **out, bool alloc_bytes)
 {
     TSR_REQUIRE(ctx && frame_offsets && out, "tsr_corpus_create: null pointer");
     *out = nullptr;
@@ -429,13 +536,7 @@ int tsr_corpus_create_empty(tsr_ctx *ctx, const int64_t *frame_offsets, int64_t 
     // resident form: 0/1 bytes, rows of Dp = round_up(D,16) bytes, zeroed slack behind the
     // last row (tiles of the scoring kernels may read, never use, up to ~48 rows past it)
     cp->Dp = (int)((D + 15) / 16 * 16);
-    const size_t body = (size_t)P * cp->Dp, slack = (size_t)48 * cp->Dp + 8192;
-    int s = TSR_OK;
-    if (hipMalloc(reinterpret_cast<void **>(&cp->d_feats), body + slack) != hipSuccess ||
-        hipMemsetAsync(cp->d_feats + body, 0, slack, ctx->stream) != hipSuccess) {
-        tsr_set_error("tsr_corpus_create: cannot allocate %zu bytes of device memory", body + slack);
-        s = TSR_ERR_HIP;
-    }
+    int s = alloc_bytes ? corpus_alloc_bytes(ctx, cp) : TSR_OK;
     if (s == TSR_OK) s = dev_upload(ctx, &cp->d_utt_beg, ub.data(), ub.size());
     if (s == TSR_OK) s = dev_upload(ctx, &cp->d_utt_end, ue.data(), ue.size(), 256 * sizeof(int32_t));  // zeroed slack: tiles read past P
     if (s == TSR_OK) s = dev_upload<float>(ctx, &cp->d_scores, nullptr, 0, (size_t)P * 4);
@@ -488,6 +589,7 @@ TSR_API int tsr_corpus_destroy(tsr_corpus *cp)
     (void)hipSetDevice(cp->device);
     (void)hipDeviceSynchronize();
     dev_free(cp->d_feats);
+    dev_free(cp->d_bits);
     dev_free(cp->d_utt_beg);
     dev_free(cp->d_utt_end);
     dev_free(cp->d_scores);
@@ -532,11 +634,10 @@ static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp,
         // Two limbs on narrow feature rows (an odd number <= 23 of 16-byte slots: the edge features of BASELINE
         // configs 1, 2 and 4): the tap-pair kernel (detect_mfma_tap2.inc: two taps folded into K, half the skew
         // emission per matrix instruction) -- config 2: 7 % faster than the interleaved kernel, config 4: 10 %.
-        // Wider rows, and filters too long for its LDS ring, stay on the interleaved kernel.  TSR_FASTK=tap2 /
-        // TSR_FASTK=old force one or the other (read per launch: A/B measurements inside one process).
-        const char *e = getenv("TSR_FASTK");
-        bool want = e && e[0] == 't';
-        if (!e || (e[0] != 't' && e[0] != 'o')) {
+        // Wider rows, and filters too long for its LDS ring, stay on the interleaved kernel.  The context option
+        // TSR_OPT_FAST_KERNEL forces one or the other (A/B measurements inside one process).
+        bool want = ctx->opt_fast_kernel == TSR_FAST_KERNEL_TAP2;
+        if (ctx->opt_fast_kernel == TSR_OPT_AUTO) {
             const int nkb2 = cp->Dp / 16;
             want = (nkb2 & 1) && nkb2 <= 23;
         }
@@ -561,12 +662,15 @@ static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp,
     }
     void *raw = nullptr;
     TSR_TRY(tsr_scratch(ctx, SLOT_RAW, (size_t)bank->M * cp->P * sizeof(float), &raw));
-    // the reference's sums bit for bit: on the matrix cores where the bank has that form (TSR_EXACTK=valu keeps the
-    // vector kernel, for A/B measurements; read per launch), otherwise one lane per window
+    // the reference's sums bit for bit: on the matrix cores where the bank has that form (the context option
+    // TSR_OPT_EXACT_KERNEL = TSR_EXACT_KERNEL_VALU keeps the vector kernel, for A/B measurements), otherwise one lane
+    // per window
     int se = TSR_ERR_UNSUPPORTED;
-    const char *ek = getenv("TSR_EXACTK");
-    if (!(ek && ek[0] == 'v')) se = tsr_launch_exact_bank_mfma(ctx, bank, cp, (float *)raw);
-    if (se == TSR_ERR_UNSUPPORTED) se = tsr_launch_exact_bank(ctx, bank, cp->d_feats, cp->P, cp->Dp, (float *)raw);
+    if (ctx->opt_exact_kernel != TSR_EXACT_KERNEL_VALU) se = tsr_launch_exact_bank_mfma(ctx, bank, cp, (float *)raw);
+    if (se == TSR_ERR_UNSUPPORTED) {
+        TSR_TRY(tsr_corpus_need_bytes(ctx, cp));
+        se = tsr_launch_exact_bank(ctx, bank, cp->d_feats, cp->P, cp->Dp, (float *)raw);
+    }
     TSR_TRY(se);
     return tsr_launch_bank_epilogue(ctx, bank, (const float *)raw, cp->P, cp->d_utt_end, flags,
                                     d_all ? nullptr : cp->d_scores, d_all ? nullptr : cp->d_ids, d_all);
@@ -792,6 +896,7 @@ TSR_API int tsr_corpus_classify_isolated(tsr_ctx *ctx, const tsr_bank *bank, con
     TSR_HIP(hipMemcpyAsync(d_ends, ends.data(), (size_t)W * 8, hipMemcpyHostToDevice, ctx->stream));
     TSR_HIP(hipMemcpyAsync(d_first, it.data(), (size_t)NW * 24, hipMemcpyHostToDevice, ctx->stream));
     TSR_HIP(hipMemcpyAsync(d_left, left.data(), (size_t)NW * 4, hipMemcpyHostToDevice, ctx->stream));
+    TSR_TRY(tsr_corpus_need_bytes(ctx, cp));
     TSR_TRY(tsr_launch_isolated_windows(ctx, bank, cp->d_feats, cp->Dp, (const float *)d_bgd, d_first, d_first + NW,
                                         d_first + 2 * NW, d_left, NW, (float *)d_all));
     TSR_TRY(tsr_launch_window_argmax(ctx, (const float *)d_all, NW, (int)bank->M, d_starts, d_ends, W, d_score, d_loc, d_tid));
@@ -1213,6 +1318,7 @@ TSR_API int tsr_corpus_weighted_sums(tsr_ctx *ctx, const tsr_corpus *cp, const f
     TSR_TRY(tsr_scratch(ctx, SLOT_RAW, (size_t)S * K * D * 4, &dP));
     TSR_TRY(tsr_scratch(ctx, SLOT_OUT, (size_t)(K * D) * 4, &dO));
     TSR_HIP(hipMemcpyAsync(dA, weights, (size_t)(P * K) * 4, hipMemcpyHostToDevice, ctx->stream));
+    TSR_TRY(tsr_corpus_need_bytes(ctx, cp));
     TSR_TRY(tsr_launch_mstep(ctx, cp->d_feats, P, (int)D, cp->Dp, (const float *)dA, (int)K, (float *)dP, S, (float *)dO));
     TSR_HIP(hipMemcpyAsync(out, dO, (size_t)(K * D) * 4, hipMemcpyDeviceToHost, ctx->stream));
     TSR_HIP(hipStreamSynchronize(ctx->stream));
@@ -1238,6 +1344,7 @@ static int mixture_scores_device(tsr_ctx *ctx, const tsr_corpus *cp, const float
     TSR_TRY(tsr_scratch(ctx, SLOT_AUX, (size_t)K * 8, &d_c));
     TSR_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     TSR_HIP(hipMemcpyAsync(d_c, consts, (size_t)K * 8, hipMemcpyHostToDevice, ctx->stream));
+    TSR_TRY(tsr_corpus_need_bytes(ctx, cp));
     TSR_TRY(tsr_launch_mixture_scores(ctx, cp->d_feats, cp->P, (int)D, cp->Dp, (const float *)d_tab, Dq, (const double *)d_c, K, d_all));
     TSR_HIP(hipStreamSynchronize(ctx->stream));  // (the host staging vector dies here)
     return TSR_OK;
@@ -1317,6 +1424,7 @@ TSR_API int tsr_mixture_m_step(tsr_ctx *ctx, tsr_corpus *cp, double *weights, fl
     void *dP = nullptr, *dO = nullptr;
     TSR_TRY(tsr_scratch(ctx, SLOT_RAW, (size_t)S * K * D * 4, &dP));
     TSR_TRY(tsr_scratch(ctx, SLOT_OUT, (size_t)(K * D) * 4, &dO));
+    TSR_TRY(tsr_corpus_need_bytes(ctx, cp));
     TSR_TRY(tsr_launch_mstep(ctx, cp->d_feats, P, (int)D, cp->Dp, cp->d_aff, (int)K, (float *)dP, S, (float *)dO));
     TSR_HIP(hipMemcpyAsync(sums, dO, (size_t)(K * D) * 4, hipMemcpyDeviceToHost, ctx->stream));
     TSR_HIP(hipStreamSynchronize(ctx->stream));
@@ -1717,8 +1825,22 @@ TSR_API int tsr_corpus_part_features(tsr_ctx *ctx, const tsr_parts *parts, const
         un0[(size_t)n] = (int32_t)(T >= parts->P0 ? T - parts->P0 + 1 : 0);
     }
     // the output corpus object (features are produced on the device, not uploaded)
+    // Resident form of the result: bit rows (an eighth of the bytes to write here and to read in the bank pass) whenever
+    // the dilation kernel can write them; byte rows are made from them on first use by anything that wants bytes.
+    const int Dp_new = (int)((O1 * K + 15) / 16 * 16), Bp_new = (int)(((O1 * K + 7) / 8 + 15) / 16 * 16);
+    const bool want_bits = ctx->opt_part_layout != TSR_PART_LAYOUT_BYTES && tsr_spread_packs_bits(N1, r0, K, Dp_new, Bp_new);
+    TSR_REQUIRE(want_bits || ctx->opt_part_layout != TSR_PART_LAYOUT_BITS,
+                "tsr_corpus_part_features: TSR_PART_LAYOUT_BITS, but the dilation cannot write bit rows for K=%lld, r0=%d", (long long)K, r0);
+    TSR_TRY(tsr_corpus_need_bytes(ctx, edges));
     tsr_corpus *cp = nullptr;
-    TSR_TRY(tsr_corpus_create_empty(ctx, ooff.data(), N, O1 * K, &cp));
+    TSR_TRY(tsr_corpus_create_empty(ctx, ooff.data(), N, O1 * K, &cp, !want_bits));
+    if (want_bits) {
+        const int sb = tsr_corpus_alloc_bits(ctx, cp);
+        if (sb != TSR_OK) {
+            tsr_corpus_destroy(cp);
+            return sb;
+        }
+    }
     void *dA = nullptr, *dRow = nullptr, *dG = nullptr, *dGm = nullptr, *dGeo = nullptr;
     int s = tsr_scratch(ctx, SLOT_AUX, (size_t)std::max<int64_t>(edges->P * N1, 1) * 4, &dA);
     if (s == TSR_OK) s = tsr_scratch(ctx, SLOT_W, (size_t)std::max<int64_t>(P_out, 1) * 12, &dRow);
@@ -1774,7 +1896,7 @@ TSR_API int tsr_corpus_part_features(tsr_ctx *ctx, const tsr_parts *parts, const
     }
     if (s == TSR_OK && P_out > 0)
         s = tsr_launch_spread_stream(ctx, (const int32_t *)dA, N1, r0, r1, K, g0, g1, O1, P_out, d_src_row,
-                                     d_src_lo, d_src_hi, (const uint8_t *)dG, (const uint64_t *)dGm, cp->Dp, cp->d_feats);
+                                     d_src_lo, d_src_hi, (const uint8_t *)dG, (const uint64_t *)dGm, cp->Dp, cp->d_feats, cp->d_bits, cp->Bp);
     int work_host[2] = {0, -1};
     if (s == TSR_OK && used_mfma &&
         hipMemcpyAsync(work_host, dWork, sizeof(work_host), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
@@ -1798,10 +1920,19 @@ TSR_API int tsr_corpus_download_feats(tsr_ctx *ctx, const tsr_corpus *cp, uint8_
 {
     TSR_REQUIRE(ctx && cp && (feats || cp->P == 0), "tsr_corpus_download_feats: null pointer");
     TSR_HIP(hipSetDevice(ctx->device));
+    TSR_TRY(tsr_corpus_need_bytes(ctx, cp));
     if (cp->P)
         TSR_HIP(hipMemcpy2DAsync(feats, (size_t)cp->D, cp->d_feats, (size_t)cp->Dp, (size_t)cp->D, (size_t)cp->P,
                                  hipMemcpyDeviceToHost, ctx->stream));
     TSR_HIP(hipStreamSynchronize(ctx->stream));
+    return TSR_OK;
+}
+
+TSR_API int tsr_corpus_layout(const tsr_corpus *cp, int *layout, int64_t *feature_bytes)
+{
+    TSR_REQUIRE(cp, "tsr_corpus_layout: null corpus");
+    if (layout) *layout = (cp->d_feats ? 1 : 0) | (cp->d_bits ? 2 : 0);
+    if (feature_bytes) *feature_bytes = (int64_t)((cp->d_feats ? cp->feats_alloc : 0) + (cp->d_bits ? cp->bits_alloc : 0));
     return TSR_OK;
 }
 

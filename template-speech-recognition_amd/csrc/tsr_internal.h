@@ -56,6 +56,8 @@ struct tsr_ctx {
     tsr_devbuf pinned;      // page-locked host staging for large downloads (see tsr_download)
     void *comm = nullptr;   // ncclComm_t when tsr_dist_init has run
     int nranks = 1, rank = 0;
+    // kernel-choice options (include/tsr.h: tsr_ctx_set_option); defaults from the environment at creation only
+    int opt_fast_kernel = 0, opt_exact_kernel = 0, opt_part_layout = 0, opt_xcd_map = 1;
 };
 
 int tsr_scratch(tsr_ctx *ctx, int slot, size_t bytes, void **out);
@@ -63,7 +65,7 @@ int tsr_scratch(tsr_ctx *ctx, int slot, size_t bytes, void **out);
 // buffer (a D2H straight into fresh pageable memory re-pins the pages on every call: 0.4 vs 5 ms for 3 MB).
 int tsr_download(tsr_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 int tsr_corpus_create_empty(tsr_ctx *ctx, const int64_t *frame_offsets, int64_t N, int64_t D,
-                            struct tsr_corpus **out);
+                            struct tsr_corpus **out, bool alloc_bytes = true);
 
 // ---- bank ---------------------------------------------------------------------
 // Exact path: templates in groups of TSR_MG; group g holds, for every (tau, d),
@@ -131,6 +133,13 @@ struct tsr_corpus {
     int64_t planes_nb = 0;           // blocks of 32 frames per parity the planes cover
     uint16_t *d_feats_bf16 = nullptr; // bf16 copy of the frames (rows of bf16_stride bytes), built on first use by TSR_BF16
     int bf16_stride = 0;
+    size_t feats_alloc = 0, bf16_alloc = 0;  // bytes allocated behind d_feats / d_feats_bf16 (frames + zeroed slack)
+    // Bit rows [P][Bp]: bit d of a frame's row (little-endian dwords) = its feature d; Bp = round_up(ceil(D/8), 16).
+    // The resident form tsr_corpus_part_features leaves behind (an eighth of the byte form).  A corpus that has
+    // them may lack d_feats until something needs byte rows (tsr_corpus_need_bytes).
+    uint8_t *d_bits = nullptr;
+    int Bp = 0;
+    size_t bits_alloc = 0;
     // Bernoulli mixture: the posterior component probabilities the latest E-step left on the device
     float *d_aff = nullptr;          // [P][aff_K]
     int64_t aff_K = 0, aff_cap = 0;  // columns in use; capacity in floats
@@ -152,6 +161,28 @@ struct tsr_parts {
     int32_t *d_kc = nullptr;  // [half 2][mt 2][16]: (base sum << 6) | part
     int64_t last_locations = 0, last_rechecked = -1;  // of the latest tsr_corpus_part_features (-1: VALU kernel ran)
 };
+
+// Read-ahead bound of the bank kernels' frame staging.  A workgroup stages whole 32-row tiles by LDS-DMA, AH tiles
+// ahead of the one it computes, but only tiles t < nT = ceil((r1 - o0) / 32) of its segment, and r1 <= P
+// (build_plan): the first row of the last staged tile is a frame of the corpus, at most row P - 1.  From that row a
+// tile copy reads `tile_bytes` contiguous bytes (flat rows: LDS row = resident row) or, row by row,
+// ceil(tile_bytes / SB) rows of src_slots 16-byte slots at a stride of Dp bytes.  So the staging never reads at or
+// beyond the offset returned here (relative to the first frame of the array it reads, `phase_off` bytes into each
+// row for K-phases) -- which has to lie inside the allocation: frames + zeroed slack.  Checked before every launch
+// (TSR_REQUIRE), for the resident bytes and for the bf16 copy alike.
+static inline size_t tsr_staging_read_end(int64_t P, int Dp, int SB, int src_slots, int tile_bytes, bool flat, size_t phase_off)
+{
+    if (P <= 0) return 0;
+    const size_t first = (size_t)(P - 1) * (size_t)Dp + phase_off;
+    if (flat) return first + (size_t)tile_bytes;
+    const size_t rows = ((size_t)tile_bytes / 16 + (size_t)(SB >> 4) - 1) / (size_t)(SB >> 4);
+    return first + (rows - 1) * (size_t)Dp + (size_t)src_slots * 16;
+}
+
+// Byte rows of a corpus that so far holds only bit rows (unpacked on the device, kept); no-op otherwise.
+int tsr_corpus_need_bytes(tsr_ctx *ctx, const struct tsr_corpus *cp);
+// Bit rows for a corpus (allocation + zeroed slack only; the caller fills them).
+int tsr_corpus_alloc_bits(tsr_ctx *ctx, struct tsr_corpus *cp);
 
 // ---- kernels' host entry points (device pointers, enqueue on ctx->stream) -----
 // detect_exact.hip
@@ -232,7 +263,8 @@ int tsr_launch_spread_graph(tsr_ctx *ctx, uint8_t *d_X, int64_t n_loc, int64_t K
 int tsr_launch_code_parts_stream(tsr_ctx *ctx, const tsr_parts *parts, const uint8_t *d_X, int64_t P,
                                  int64_t X1, int Dp, const int32_t *d_utt_end, int threshold, int fast,
                                  int32_t *d_argmax);
+bool tsr_spread_packs_bits(int64_t N1, int r0, int64_t K, int Dp_out, int Bp);
 int tsr_launch_spread_stream(tsr_ctx *ctx, const int32_t *d_A, int64_t N1, int r0, int r1, int64_t K,
                              int g0, int g1, int64_t O1, int64_t P_out, const int32_t *d_src_row,
                              const int32_t *d_src_lo, const int32_t *d_src_hi, const uint8_t *d_graph,
-                             const uint64_t *d_graph_masks, int Dp_out, uint8_t *d_out);
+                             const uint64_t *d_graph_masks, int Dp_out, uint8_t *d_out, uint8_t *d_out_bits = nullptr, int Bp = 0);

@@ -10,6 +10,12 @@ TSR_OK, TSR_ERR_INVALID, TSR_ERR_HIP, TSR_ERR_NO_DEVICE, TSR_ERR_UNSUPPORTED, TS
     TSR_ERR_RCCL = range(7)
 TSR_EXACT, TSR_FAST, TSR_W24, TSR_BF16 = 0, 1, 2, 4
 TSR_PARTS_AUTO, TSR_PARTS_VALU, TSR_PARTS_MFMA = 0, 1, 2
+# context options (include/tsr.h: tsr_ctx_set_option)
+TSR_OPT_FAST_KERNEL, TSR_OPT_EXACT_KERNEL, TSR_OPT_PART_LAYOUT, TSR_OPT_XCD_MAP = 1, 2, 3, 4
+TSR_OPT_AUTO = 0
+TSR_FAST_KERNEL_TAP2, TSR_FAST_KERNEL_INTERLEAVED = 1, 2
+TSR_EXACT_KERNEL_VALU, TSR_EXACT_KERNEL_MFMA = 1, 2
+TSR_PART_LAYOUT_BYTES, TSR_PART_LAYOUT_BITS = 1, 2
 
 _i32, _i64, _int, _p, _f = C.c_int32, C.c_int64, C.c_int, C.c_void_p, C.c_float
 _pp = C.POINTER(C.c_void_p)
@@ -21,6 +27,8 @@ SIGNATURES = {
     "tsr_ctx_create": [_int, _pp],
     "tsr_ctx_destroy": [_p],
     "tsr_ctx_sync": [_p],
+    "tsr_ctx_set_option": [_p, _int, _int],
+    "tsr_ctx_get_option": [_p, _int, C.POINTER(_int)],
     "tsr_timer_start": [_p],
     "tsr_timer_stop": [_p, C.POINTER(_f)],
     "tsr_device_info": [_p, C.c_char_p, _int, C.POINTER(_int), C.POINTER(_i64)],
@@ -70,6 +78,7 @@ SIGNATURES = {
     "tsr_corpus_part_features": [_p, _p, _p, _int, _int, _int, _int, _p, _int, _int, _pp],
     "tsr_corpus_download_feats": [_p, _p, _p],
     "tsr_corpus_shape": [_p, C.POINTER(_i64), C.POINTER(_i64), _p],
+    "tsr_corpus_layout": [_p, C.POINTER(_int), C.POINTER(_i64)],
     "tsr_dist_unique_id": [C.c_char_p],
     "tsr_dist_init": [_p, C.c_char_p, _int, _int],
     "tsr_dist_finalize": [_p],

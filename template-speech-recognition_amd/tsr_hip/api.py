@@ -55,6 +55,30 @@ class Context:
         check(lib().tsr_device_info(self._h, name, 128, C.byref(cus), C.byref(hbm)))
         return dict(name=name.value.decode(), cus=int(cus.value), hbm_bytes=int(hbm.value))
 
+    # ---- kernel-choice options (tsr_ctx_set_option): same results, different kernels ------
+    def set_option(self, option, value):
+        check(lib().tsr_ctx_set_option(self._h, int(option), int(value)))
+
+    def get_option(self, option):
+        v = C.c_int()
+        check(lib().tsr_ctx_get_option(self._h, int(option), C.byref(v)))
+        return int(v.value)
+
+    def option(self, option, value):
+        """`with ctx.option(TSR_OPT_FAST_KERNEL, TSR_FAST_KERNEL_INTERLEAVED): ...` -- set, run, restore."""
+        ctx = self
+
+        class _Scoped:
+            def __enter__(self):
+                self.old = ctx.get_option(option)
+                ctx.set_option(option, value)
+                return ctx
+
+            def __exit__(self, *exc):
+                ctx.set_option(option, self.old)
+                return False
+        return _Scoped()
+
     # ---- multi-GPU (one process per GPU; see tsr_hip.dist) -------------------------
     def dist_init(self, unique_id, nranks, rank):
         check(lib().tsr_dist_init(self._h, unique_id, int(nranks), int(rank)))
@@ -251,6 +275,12 @@ class Corpus:
                                              int(spread[0]), int(spread[1]), ptr(g), int(grid[0]),
                                              int(grid[1]), C.byref(h)))
         return Corpus._adopt(h, self.ctx)
+
+    def layout(self):
+        """What is resident: {"bytes": bool, "bits": bool, "feature_bytes": device bytes of those forms}."""
+        lay, nb = C.c_int(), C.c_int64()
+        check(lib().tsr_corpus_layout(self._h, C.byref(lay), C.byref(nb)))
+        return {"bytes": bool(lay.value & 1), "bits": bool(lay.value & 2), "feature_bytes": int(nb.value)}
 
     def download_feats(self):
         """The resident feature bytes as u8 [sum T, D] (0/1)."""

@@ -298,10 +298,8 @@ def test_config2_full_size_properties(mods, oracle):
     bank = tsr_hip.Bank(c["bank"])
     feats, offs = c["feats"], c["offsets"]
     s, a = bank.score(feats, offs)
-    rng = np.random.default_rng(0)
-    for n in rng.choice(1000, size=12, replace=False):
-        so, ao = oracle.score_bank(feats[offs[n]:offs[n + 1]], c["bank"])
-        assert np.array_equal(s[offs[n]:offs[n + 1]], so) and np.array_equal(a[offs[n]:offs[n + 1]], ao)
+    so, ao = _oracle_corpus(oracle, c, "config2a")          # every one of the 200 000 frames, bit for bit
+    assert np.array_equal(s, so) and np.array_equal(a, ao)
     cf = np.array([np.float32(cc) for _, cc in c["bank"]])
     tail = s.reshape(1000, 200)[:, 169:]
     assert np.all(tail == cf.max()) and np.all(a.reshape(1000, 200)[:, 169:] == int(np.argmax(cf)))
@@ -310,11 +308,23 @@ def test_config2_full_size_properties(mods, oracle):
 
 
 # ---- the benchmarked kernel under a checker at the benchmark's size -------------------------------
-def _fast_all_frames(tsr_hip, oracle, c, flags, n_oracle=12, seed=0, check_exact=False):
+_ORACLE_CORPUS = {}
+
+
+def _oracle_corpus(oracle, c, key):
+    """The CPU oracle over EVERY frame of a corpus (config 2: ~9 s on one core), computed once per
+    configuration and shared by the tests of this module."""
+    if key not in _ORACLE_CORPUS:
+        _ORACLE_CORPUS[key] = oracle.score_corpus(c["feats"], c["offsets"], c["bank"])
+    return _ORACLE_CORPUS[key]
+
+
+def _fast_all_frames(tsr_hip, oracle, c, flags, n_oracle=12, seed=0, check_exact=False, oracle_key=None):
     """Every frame of the corpus, fused scores + ids AND the per-template scores, TSR_FAST[|W24] against
-    TSR_EXACT (the bit-identical kernel, itself held to the oracle elsewhere and on a sample here);
-    then a seeded sample of utterances straight against the oracle.  At this size the MFMA kernel runs
-    its steady-state iteration, cuts segments inside utterances and reads halo rows."""
+    TSR_EXACT (the bit-identical kernel); then straight against the oracle -- over ALL frames when
+    `oracle_key` names the corpus (the HIP paths are then not only held against each other), else on a
+    seeded sample of utterances.  At this size the MFMA kernel runs its steady-state iteration, cuts
+    segments inside utterances and reads halo rows."""
     feats, offs = c["feats"], c["offsets"]
     P, N = int(offs[-1]), len(offs) - 1
     bank = tsr_hip.Bank(c["bank"])
@@ -333,6 +343,14 @@ def _fast_all_frames(tsr_hip, oracle, c, flags, n_oracle=12, seed=0, check_exact
         assert clear.mean() > 0.5
     # the fused pass and the all-scores pass of the fast path agree bit for bit (exact integer sums)
     assert np.array_equal(allf.max(0), sf)
+    if oracle_key is not None:
+        so, ao = _oracle_corpus(oracle, c, oracle_key)
+        assert np.array_equal(se, so) and np.array_equal(ae, ao)      # the exact kernel: every frame, bit for bit
+        assert rel_err(sf, so) <= TOL                                   # the benchmarked kernel: every frame
+        margin = np.sort(alle, axis=0)[-2:] if alle.shape[0] > 1 else None
+        if margin is not None:
+            clear = (margin[1] - margin[0]) > TOL * np.maximum(np.abs(margin[1]), 1.0)
+            assert np.array_equal(af[clear], ao[clear])
     rng = np.random.default_rng(seed)
     lens = np.diff(offs)
     cand = np.flatnonzero(lens > 0)
@@ -355,7 +373,8 @@ def test_config2_full_size_fast_all_frames(mods, oracle, L, flags):
     tsr_hip = mods[3]
     from tsr_hip import synth
     c = synth.corpus(2, N=1000, T=200, F=45, E=8, M=8, L=L)
-    _fast_all_frames(tsr_hip, oracle, c, flags, check_exact=(flags == 1))
+    _fast_all_frames(tsr_hip, oracle, c, flags, check_exact=(flags == 1),
+                     oracle_key="config2a" if L == 32 else "config2b")
 
 
 @pytest.mark.parametrize("flags", [1, 3], ids=["fast16", "fast24"])
@@ -595,6 +614,65 @@ def test_part_coder_mfma(mods, oracle, case):
     assert np.array_equal(got[tsr_hip.TSR_PARTS_MFMA], got[tsr_hip.TSR_PARTS_VALU])
 
 
+@pytest.mark.parametrize("case", [
+    dict(K=50, F=45, Ts=[200, 64, 31, 150, 200, 7, 4, 90], thr=12, spread=(2, 2), grid=(1, 1), M=8, L=32, bit_path=True),   # config-3 geometry: 6 K-phases
+    dict(K=50, F=45, Ts=[120, 77], thr=10, spread=(5, 5), grid=(5, 5), M=3, L=[9, 14, 5]),                         # waliji variant (D = 450)
+    dict(K=6, F=14, Ts=[40, 18, 5], thr=8, spread=(1, 2), grid=(1, 1), M=5, L=[9, 12, 16, 20, 11], graph=True),    # narrow rows + closure
+    dict(K=63, F=16, Ts=[28, 9, 33], thr=15, spread=(0, 0), grid=(2, 1), M=9, L=[5, 6, 7, 8, 9, 10, 11, 12, 4]),   # two template groups
+    dict(K=20, F=21, Ts=[300] * 40, thr=10, spread=(2, 2), grid=(1, 1), M=8, L=[20, 24, 28, 32, 36, 40, 44, 48], bit_path=True),   # 12 000 frames: interior tiles, cut segments
+])
+def test_part_corpus_bit_rows(mods, oracle, case):
+    """tsr_corpus_part_features leaves the part features resident as BIT rows (an eighth of the bytes) and the
+    two-limb TSR_FAST pass reads them as they are.  Held against the byte-row layout of the same chain
+    (TSR_OPT_PART_LAYOUT): identical features, identical TSR_FAST scores and ids (exact integer sums), TSR_EXACT bit
+    for bit -- and both against the oracle chain + oracle scores."""
+    tsr_hip = mods[3]
+    from tsr_hip import synth
+    ctx = tsr_hip.default_ctx()
+    rng = np.random.default_rng(case["K"] * 100 + case["F"])
+    K, F, Ts = case["K"], case["F"], case["Ts"]
+    edges = [synth.features(rng, T, rng.uniform(0.05, 0.45, size=(F, 8))) for T in Ts]
+    offs = np.concatenate(([0], np.cumsum(Ts))).astype(np.int64)
+    lp, lip = synth.parts(rng, K)
+    graph = None
+    if case.get("graph"):
+        graph = (rng.random((K, K)) < 0.2).astype(np.uint8)
+    corpus = tsr_hip.Corpus(np.concatenate(edges).reshape(int(offs[-1]), -1), offs)
+    parts = tsr_hip.Parts(lp, lip)
+    pcs = {}
+    for name, opt in (("bits", tsr_hip.TSR_PART_LAYOUT_BITS), ("bytes", tsr_hip.TSR_PART_LAYOUT_BYTES)):
+        with ctx.option(tsr_hip.TSR_OPT_PART_LAYOUT, opt):
+            pcs[name] = corpus.part_features(parts, case["thr"], spread=case["spread"], grid=case["grid"], graph=graph)
+    lay = pcs["bits"].layout()
+    assert lay == dict(bytes=False, bits=True, feature_bytes=lay["feature_bytes"]) and pcs["bytes"].layout()["bits"] is False
+    if case.get("bit_path"):
+        assert lay["feature_bytes"] < pcs["bytes"].layout()["feature_bytes"] / 3
+    D = pcs["bits"].D
+    bank_cs = synth.bank(rng, synth.background(rng, (D // K, K)), case["L"] if isinstance(case["L"], list) else [case["L"]] * case["M"])
+    bank = tsr_hip.Bank(bank_cs)
+    res = {}
+    for name, pc in pcs.items():
+        pc.score(bank, tsr_hip.TSR_FAST)
+        res[name] = pc.download() + (pc.score_all(bank, tsr_hip.TSR_FAST),)
+    if case.get("bit_path"):                                        # eight column tiles on wide rows: the bit-reading pass ran
+        assert pcs["bits"].layout()["bytes"] is False               # ... and nothing made byte rows
+    for a, b in zip(res["bits"], res["bytes"]):
+        assert np.array_equal(a, b)
+    feats = pcs["bits"].download_feats()                            # (unpacks the bit rows)
+    assert np.array_equal(feats, pcs["bytes"].download_feats())
+    if graph is None:
+        want = _oracle_part_chain(oracle, edges, lp, lip, case["thr"], case["spread"], case["grid"], False, K)
+        assert np.array_equal(feats, np.concatenate([w.reshape(w.shape[0], D) for w in want]))
+    po = pcs["bits"].offsets
+    so, ao = oracle.score_corpus(feats, po, bank_cs)
+    pcs["bits"].score(bank, tsr_hip.TSR_EXACT)
+    se, ae = pcs["bits"].download()
+    assert np.array_equal(se, so) and np.array_equal(ae, ao)
+    assert rel_err(res["bits"][0], so) <= TOL
+    for pc in pcs.values():
+        pc.close()
+
+
 def test_part_coder_mfma_unsupported_falls_back(mods, oracle):
     tsr_hip = mods[3]
     from tsr_hip import synth
@@ -639,7 +717,8 @@ def test_config3_fullsize_coders_agree(mods, oracle):
             pc_mfma = pc
     assert np.array_equal(out[tsr_hip.TSR_PARTS_MFMA], out[tsr_hip.TSR_PARTS_VALU])
     got = out[tsr_hip.TSR_PARTS_MFMA].reshape(N, T - 4, (F - 4) * K)
-    for n in rng.choice(N, size=3, replace=False):
+    sample = rng.choice(N, size=32, replace=False)
+    for n in sample:
         want = _oracle_part_chain(oracle, [feats[offs[n]:offs[n + 1]]], lp, lip, 12, (2, 2), (1, 1), False, K)[0]
         assert np.array_equal(got[n], want.reshape(T - 4, -1))
     bank_cs = synth.bank(rng, synth.background(rng, (F - 4, K)), [32] * 8)
@@ -649,10 +728,11 @@ def test_config3_fullsize_coders_agree(mods, oracle):
     pc_mfma.score(bank, tsr_hip.TSR_FAST)
     sf, af = pc_mfma.download()
     assert rel_err(sf, se) <= TOL
-    n0 = int(rng.integers(N))
-    so, ao = oracle.score_bank(got[n0], bank_cs)
-    sl = slice(pc_mfma.offsets[n0], pc_mfma.offsets[n0 + 1])
-    assert np.array_equal(se[sl], so) and np.array_equal(ae[sl], ao)
+    for n0 in sample[:8]:                                 # the D = 2050 bank on the part corpus, against the oracle
+        so, ao = oracle.score_bank(got[n0], bank_cs)
+        sl = slice(pc_mfma.offsets[n0], pc_mfma.offsets[n0 + 1])
+        assert np.array_equal(se[sl], so) and np.array_equal(ae[sl], ao)
+        assert rel_err(sf[sl], so) <= TOL
 
 
 # ---- phone-window classification ------------------------------------------------
@@ -822,6 +902,77 @@ def test_config4_share_fullsize_properties(mods, oracle):
     cf = np.array([np.float32(cc) for _, cc in c["bank"]])
     tail = se.reshape(1250, 200)[:, 200 - min(L) + 1:]    # frames that are tail for EVERY template
     assert np.all(tail == cf.max())
+
+
+def test_config4_full_size_on_one_gpu(mods, oracle):
+    """BASELINE config 4 at its stated size -- 10 000 utterances x 200 frames x 64 templates (L_m in 24..48) --
+    scored on ONE device (720 MB of features; the eight-GPU run shards exactly these utterances): the MFMA path
+    against the bit-exact kernel over all 2 000 000 frames, batching invariance (any rank's shard scored alone
+    gives the rows of the whole), the tail rule, and 32 utterances spread over the corpus against the oracle."""
+    tsr_hip = mods[3]
+    from tsr_hip import synth
+    from tsr_hip import dist as tdist
+    L = [24 + (7 * m) % 25 for m in range(64)]
+    N, T = 10000, 200
+    c = synth.corpus(4, N=N, T=T, F=45, E=8, M=64, L=L)
+    feats, offs = c["feats"], c["offsets"]
+    bank = tsr_hip.Bank(c["bank"])
+    corpus = tsr_hip.Corpus(feats, offs)
+    corpus.score(bank, tsr_hip.TSR_EXACT)
+    se, ae = corpus.download()
+    corpus.score(bank, tsr_hip.TSR_FAST)
+    sf, af = corpus.download()
+    corpus.close()
+    assert rel_err(sf, se) <= TOL
+    assert (af != ae).mean() < 1e-3                       # only near-ties may resolve differently
+    cf = np.array([np.float32(cc) for _, cc in c["bank"]])
+    assert np.all(se.reshape(N, T)[:, T - min(L) + 1:] == cf.max())     # frames that are tail for EVERY template
+    # the shard of rank 5 of 8, scored alone (what that rank would do): the same rows
+    b = tdist.shard_utterances(np.diff(offs), 8)
+    lo, hi = int(offs[b[5]]), int(offs[b[6]])
+    shard = tsr_hip.Corpus(feats[lo:hi], offs[b[5]:b[6] + 1] - lo)
+    shard.score(bank, tsr_hip.TSR_FAST)
+    s5, a5 = shard.download()
+    shard.score(bank, tsr_hip.TSR_EXACT)
+    e5, i5 = shard.download()
+    shard.close()
+    assert np.array_equal(s5, sf[lo:hi]) and np.array_equal(a5, af[lo:hi])
+    assert np.array_equal(e5, se[lo:hi]) and np.array_equal(i5, ae[lo:hi])
+    rng = np.random.default_rng(40)
+    for n in rng.choice(N, size=32, replace=False):
+        sl = slice(int(offs[n]), int(offs[n + 1]))
+        so, ao = oracle.score_bank(feats[sl], c["bank"])
+        assert np.array_equal(se[sl], so) and np.array_equal(ae[sl], ao), n
+        assert rel_err(sf[sl], so) <= TOL, n
+
+
+def test_bf16_variants_on_the_config4_share_all_frames(mods, oracle):
+    """The size at which a round-2 development build faulted (tools/time_config45.py, bf16 hi + lo on the
+    1250-utterance M = 64 share): both bf16 variants over all 250 000 frames against TSR_EXACT.  The frame staging
+    of the bank kernels reads whole tiles up to tile_bytes - row bytes past the last frame of the array it reads; the
+    host now checks that bound against the allocation before every launch (tsr_staging_read_end)."""
+    tsr_hip = mods[3]
+    from tsr_hip import synth
+    L = [24 + (7 * m) % 25 for m in range(64)]
+    c = synth.corpus(4, N=1250, T=200, F=45, E=8, M=64, L=L)
+    bank = tsr_hip.Bank(c["bank"])
+    corpus = tsr_hip.Corpus(c["feats"], c["offsets"])
+    corpus.score(bank, tsr_hip.TSR_EXACT)
+    se, ae = corpus.download()
+    alle = corpus.score_all(bank, tsr_hip.TSR_EXACT)
+    for _ in range(2):                                    # twice: the second pass reuses the cached bf16 copy and plan
+        corpus.score(bank, tsr_hip.TSR_FAST | tsr_hip.TSR_BF16 | tsr_hip.TSR_W24)
+        s2, a2 = corpus.download()
+        assert rel_err(s2, se) <= TOL
+    top2 = np.sort(alle, axis=0)[-2:]
+    clear = (top2[1] - top2[0]) > TOL * np.maximum(np.abs(top2[1]), 1.0)
+    assert np.array_equal(a2[clear], ae[clear])
+    corpus.score(bank, tsr_hip.TSR_FAST | tsr_hip.TSR_BF16)
+    s1, _ = corpus.download()
+    assert rel_err(s1, se) <= 5e-3                        # one bf16 weight: 8 significant bits, outside the 1e-4 bar
+    x2 = corpus.score_all(bank, tsr_hip.TSR_FAST | tsr_hip.TSR_BF16 | tsr_hip.TSR_W24)
+    assert rel_err(x2, alle) <= TOL
+    corpus.close()
 
 
 # ---- edge front-end (SURVEY 8(f) N3): HIP kernel vs the NumPy restatement of edge_signal_proc.py ------
@@ -1245,7 +1396,6 @@ def test_tap_pair_kernel_parity(mods, oracle):
     (csrc/detect_mfma_kernel.inc).  Both sum the same fixed-point integers exactly -- identical scores and ids where a
     bank is one column group in both, one float32 rounding apart where templates are cut into fragments at different
     columns -- at the benchmark's size, on ragged geometry, with 64 templates and on a tiny case."""
-    import os
     tsr_hip = mods[3]
     from tsr_hip import synth
     rng = np.random.default_rng(77)
@@ -1260,13 +1410,10 @@ def test_tap_pair_kernel_parity(mods, oracle):
         bank = tsr_hip.Bank(c["bank"])
         dc = tsr_hip.Corpus(c["feats"].reshape(P, -1), c["offsets"])
         res = {}
-        for kernel in ("old", "tap2"):
-            os.environ["TSR_FASTK"] = kernel
-            try:
+        for kernel, opt in (("old", tsr_hip.TSR_FAST_KERNEL_INTERLEAVED), ("tap2", tsr_hip.TSR_FAST_KERNEL_TAP2)):
+            with tsr_hip.default_ctx().option(tsr_hip.TSR_OPT_FAST_KERNEL, opt):
                 dc.score(bank, tsr_hip.TSR_FAST)
                 res[kernel] = dc.download() + (dc.score_all(bank, tsr_hip.TSR_FAST),)
-            finally:
-                del os.environ["TSR_FASTK"]
         want, got = res["old"], res["tap2"]
         taps = sum(W.shape[0] for W, _ in c["bank"])
         if taps <= 256:   # one column group in both kernels (256 tap columns / 128 tap-pair columns)
@@ -1283,7 +1430,6 @@ def test_exact_on_matrix_cores_equals_vector_kernel_bit_for_bit(mods, oracle):
     the frames); TSR_EXACTK=valu keeps the one-lane-per-window kernel.  Same additions in the same order: every
     score of every template identical, on ragged corpora, template counts off the group size of eight, filter
     lengths from 1 to past two blocks of frames, feature counts off the 16-byte row grid, and against the oracle."""
-    import os
     tsr_hip = mods[3]
     from tsr_hip import synth
     rng = np.random.default_rng(91)
@@ -1299,13 +1445,10 @@ def test_exact_on_matrix_cores_equals_vector_kernel_bit_for_bit(mods, oracle):
         dc.score(bank, tsr_hip.TSR_EXACT)
         got = dc.download()
         got_all = dc.score_all(bank, tsr_hip.TSR_EXACT)
-        os.environ["TSR_EXACTK"] = "valu"
-        try:
+        with tsr_hip.default_ctx().option(tsr_hip.TSR_OPT_EXACT_KERNEL, tsr_hip.TSR_EXACT_KERNEL_VALU):
             dc.score(bank, tsr_hip.TSR_EXACT)
             want = dc.download()
             want_all = dc.score_all(bank, tsr_hip.TSR_EXACT)
-        finally:
-            del os.environ["TSR_EXACTK"]
         assert np.array_equal(got_all, want_all)
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
         if P <= 8000:
@@ -1332,7 +1475,6 @@ def test_padding_columns_do_not_serialise_the_ring(mods, oracle):
     mostly padding.  When padding lanes all added into one spare ring cell (same-address LDS atomics serialise) its pass
     took 10x config 2's (364 vs 36 us); with per-lane spare cells / silent padding lanes it takes 2x (two column
     groups).  Both two-limb kernels, same corpus size."""
-    import os
     tsr_hip = mods[3]
     from tsr_hip import synth
     ctx = tsr_hip.default_ctx()
@@ -1354,10 +1496,7 @@ def test_padding_columns_do_not_serialise_the_ring(mods, oracle):
 
     c2 = synth.corpus(2, N=1000, T=200, F=45, E=8, M=8, L=32)
     c2b = synth.corpus(2, N=1000, T=200, F=45, E=8, M=8, L=[20, 24, 28, 32, 36, 40, 44, 48])
-    for kernel in ("tap2", "old"):
-        os.environ["TSR_FASTK"] = kernel
-        try:
+    for kernel, opt in (("tap2", tsr_hip.TSR_FAST_KERNEL_TAP2), ("old", tsr_hip.TSR_FAST_KERNEL_INTERLEAVED)):
+        with tsr_hip.default_ctx().option(tsr_hip.TSR_OPT_FAST_KERNEL, opt):
             t2, t2b = per_launch(c2), per_launch(c2b)
-        finally:
-            del os.environ["TSR_FASTK"]
         assert t2b < 5.0 * t2, (kernel, t2, t2b)

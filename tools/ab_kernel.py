@@ -1,6 +1,7 @@
 """A/B of two builds of the bank kernel inside ONE process, interleaved rounds (cdna_hip_programming.md
-rule 24): an environment variable the library reads per launch selects the kernel.
-    python tools/ab_kernel.py TSR_FASTK old,alt [R] [rounds] [config: 2 | 2b | 3 | 4] [flags]
+rule 24): a context option (tsr_ctx_set_option) selects the kernel per launch.
+    python tools/ab_kernel.py TSR_FASTK old,tap2 [R] [rounds] [config: 2 | 2b | 3 | 4] [flags]
+    python tools/ab_kernel.py TSR_EXACTK valu,mfma ...
 Streams over R device-resident copies of the corpus (working set >> L3 for R >= 8)."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "template-speech-recognition_amd"))
@@ -8,6 +9,9 @@ import numpy as np
 import tsr_hip
 from tsr_hip import synth
 VAR, VALS = sys.argv[1], sys.argv[2].split(",")
+OPTION = {"TSR_FASTK": (tsr_hip.TSR_OPT_FAST_KERNEL, {"old": tsr_hip.TSR_FAST_KERNEL_INTERLEAVED, "tap2": tsr_hip.TSR_FAST_KERNEL_TAP2, "auto": 0}),
+          "TSR_EXACTK": (tsr_hip.TSR_OPT_EXACT_KERNEL, {"valu": tsr_hip.TSR_EXACT_KERNEL_VALU, "mfma": tsr_hip.TSR_EXACT_KERNEL_MFMA, "auto": 0}),
+          "TSR_XCD_MAP": (tsr_hip.TSR_OPT_XCD_MAP, {"0": 0, "1": 1})}[VAR]
 R = int(sys.argv[3]) if len(sys.argv) > 3 else 24
 ROUNDS = int(sys.argv[4]) if len(sys.argv) > 4 else 7
 CONF = sys.argv[5] if len(sys.argv) > 5 else "2"
@@ -28,7 +32,7 @@ res = {v: [] for v in VALS}
 out = {}
 for rnd in range(ROUNDS + 1):
     for v in VALS:
-        os.environ[VAR] = v
+        ctx.set_option(OPTION[0], OPTION[1][v])
         ctx.sync()
         ctx.timer_start()
         for _ in range(3):

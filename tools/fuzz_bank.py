@@ -40,9 +40,8 @@ for case in range(n_cases):
                 continue
             so, ao = oracle.score_bank(c["feats"][sl], c["bank"])
             ok = ok and np.array_equal(se[sl], so) and np.array_equal(ae[sl], ao)
-        os.environ["TSR_EXACTK"] = "valu"
-        sv, av = bank.score(c["feats"], c["offsets"], flags=tsr_hip.TSR_EXACT)
-        del os.environ["TSR_EXACTK"]
+        with tsr_hip.default_ctx().option(tsr_hip.TSR_OPT_EXACT_KERNEL, tsr_hip.TSR_EXACT_KERNEL_VALU):
+            sv, av = bank.score(c["feats"], c["offsets"], flags=tsr_hip.TSR_EXACT)
         msg = ("" if ok else " EXACT!=ORACLE") + ("" if np.array_equal(se, sv) and np.array_equal(ae, av) else " EXACT(mfma)!=EXACT(valu)")
     else:
         so, ao = oracle.score_corpus(c["feats"], c["offsets"], c["bank"])
@@ -50,10 +49,10 @@ for case in range(n_cases):
         msg = "" if ok else " EXACT!=ORACLE"
     for flags in ((1, 3, -1) if LARGE else (1, 3)):
         if flags == -1:   # the tap-pair kernel (falls back to the default kernel where its geometry does not fit)
-            os.environ["TSR_FASTK"] = "tap2"
+            tsr_hip.default_ctx().set_option(tsr_hip.TSR_OPT_FAST_KERNEL, tsr_hip.TSR_FAST_KERNEL_TAP2)
             flags = 1
         else:
-            os.environ.pop("TSR_FASTK", None)
+            tsr_hip.default_ctx().set_option(tsr_hip.TSR_OPT_FAST_KERNEL, tsr_hip.TSR_OPT_AUTO)
         sf, af = bank.score(c["feats"], c["offsets"], flags=flags)
         err = float(np.max(np.abs(sf - se) / np.maximum(np.abs(se), 1.0))) if len(se) else 0.0
         if err > 1e-4:
@@ -74,5 +73,5 @@ for case in range(n_cases):
     if msg:
         bad += 1
         print("case %d N=%d M=%d D=%d Ls=%s Ts=%s:%s" % (case, N, M, F * E, Ls, Ts, msg))
-os.environ.pop("TSR_FASTK", None)
+tsr_hip.default_ctx().set_option(tsr_hip.TSR_OPT_FAST_KERNEL, tsr_hip.TSR_OPT_AUTO)
 print("fuzz%s: %d cases, %d bad" % (" (large corpora)" if LARGE else "", n_cases, bad))
