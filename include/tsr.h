@@ -105,7 +105,11 @@ int tsr_timer_stop(tsr_ctx *ctx, float *elapsed_ms);
  *   TSR_OPT_PART_LAYOUT   what tsr_corpus_part_features leaves resident: AUTO (bit rows when the
  *                         dilation kernel can write them, K <= 64), TSR_PART_LAYOUT_BYTES, TSR_PART_LAYOUT_BITS
  *   TSR_OPT_XCD_MAP       XCD-aware placement of multi-group bank passes: 1 (default) / 0 */
-enum { TSR_OPT_FAST_KERNEL = 1, TSR_OPT_EXACT_KERNEL = 2, TSR_OPT_PART_LAYOUT = 3, TSR_OPT_XCD_MAP = 4 };
+enum { TSR_OPT_FAST_KERNEL = 1, TSR_OPT_EXACT_KERNEL = 2, TSR_OPT_PART_LAYOUT = 3, TSR_OPT_XCD_MAP = 4,
+       /* read-only (tsr_ctx_get_option): 0 = TSR_EXACT has not met the matrix cores on this context yet, 1 = the one-off
+        * probe (a small fixed bank scored by the matrix-core kernel and by the vector kernel) matched bit for bit,
+        * -1 = it did not and every TSR_EXACT pass of this context stays on the vector kernel (said once on stderr) */
+       TSR_INFO_EXACT_MFMA = 5 };
 enum { TSR_OPT_AUTO = 0,
        TSR_FAST_KERNEL_TAP2 = 1, TSR_FAST_KERNEL_INTERLEAVED = 2,
        TSR_EXACT_KERNEL_VALU = 1, TSR_EXACT_KERNEL_MFMA = 2,
@@ -334,7 +338,8 @@ int tsr_edge_corpus_create_masked(tsr_ctx *ctx, const double *S_cat, const uint8
  * receives the quantile values (NaN for empty blocks) -- what report_level=True returns.
  * spread_edgemap (:1397-1404) over _spread_edges (:1406-1417): every row block, in place, becomes the maximum
  * (floored at 0) over the shifts k * orientations[b] = (rows, columns), k in [-spread_length, spread_length],
- * zeros outside the block. */
+ * zeros outside the block.  orientations == NULL is spread_type='all' of _edge_map_threshold_segments (:1623-1636,
+ * :1664-1675): SciPy's maximum_filter over a (2 spread_length + 1)^2 box with zeros outside the row block. */
 int tsr_threshold_edgemap(tsr_ctx *ctx, double *E, const int64_t *row_breaks, int32_t n_blocks, int64_t T,
                           double quantile, const double *abst_threshold, int32_t convert_to_binary, double *thresholds);
 int tsr_spread_edgemap(tsr_ctx *ctx, double *E, const int64_t *row_breaks, int32_t n_blocks, int64_t T,

@@ -108,8 +108,20 @@ __global__ __launch_bounds__(256) void spread_blocks_kernel(const double *__rest
         return;
     }
     const int64_t r0 = breaks[b], F = breaks[b + 1] - r0, h = row - r0;
-    const int d0 = orient[2 * b], d1 = orient[2 * b + 1];
     double m = 0.0;
+    if (!orient) {  // spread_type 'all' (edge_signal_proc.py:1623-1636): scipy maximum_filter, (2s+1) x (2s+1), constant 0 outside the block
+        for (int k0 = -s; k0 <= s; ++k0)
+            for (int k1 = -s; k1 <= s; ++k1) {
+                const int64_t hh = h + k0, tt = t + k1;
+                if (hh >= 0 && hh < F && tt >= 0 && tt < T) {
+                    const double v = in[(r0 + hh) * T + tt];
+                    m = v > m ? v : m;
+                }
+            }
+        out[idx] = m;
+        return;
+    }
+    const int d0 = orient[2 * b], d1 = orient[2 * b + 1];
     for (int k = -s; k <= s; ++k) {
         const int64_t hh = h + (int64_t)k * d0, tt = t + (int64_t)k * d1;
         if (hh >= 0 && hh < F && tt >= 0 && tt < T) {

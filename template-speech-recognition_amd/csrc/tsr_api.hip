@@ -133,6 +133,7 @@ TSR_API int tsr_ctx_get_option(const tsr_ctx *ctx, int option, int *value)
     case TSR_OPT_EXACT_KERNEL: *value = ctx->opt_exact_kernel; return TSR_OK;
     case TSR_OPT_PART_LAYOUT: *value = ctx->opt_part_layout; return TSR_OK;
     case TSR_OPT_XCD_MAP: *value = ctx->opt_xcd_map; return TSR_OK;
+    case TSR_INFO_EXACT_MFMA: *value = ctx->exact_mfma_state; return TSR_OK;
     default: break;
     }
     tsr_set_error("tsr_ctx_get_option: unknown option %d", option);
@@ -609,6 +610,63 @@ TSR_API int tsr_corpus_frames(const tsr_corpus *cp, int64_t *total_frames)
     return TSR_OK;
 }
 
+// One-off probe per context: the bit-identity of exact_mfma_kernel with the reference's sequential f32
+// sums rests on how this chip's v_mfma_f32_16x16x4_f32 rounds (an ascending fmaf chain, one rounding per step) and on a
+// compiler that keeps the hazard distance in front of its operand selects.  Before the first TSR_EXACT pass goes to the
+// matrix cores, a small fixed bank and corpus (two template groups, lengths 1 .. 23, D off the 16-byte grid, ragged
+// utterances) are scored by both exact kernels and the raw sums compared bit for bit; on any difference the context
+// keeps to the vector kernel from then on.
+static int exact_mfma_probe(tsr_ctx *ctx)
+{
+    if (ctx->exact_mfma_state != 0) return TSR_OK;
+    ctx->exact_mfma_state = -1;  // (until proven otherwise; also stops recursion)
+    const int M = 11, D = 45, N = 4;
+    const int64_t Ts[N] = {70, 33, 41, 9};
+    std::vector<int32_t> L(M);
+    std::vector<double> c(M, 0.0);
+    std::vector<int64_t> offs(N + 1, 0);
+    for (int n = 0; n < N; ++n) offs[n + 1] = offs[n] + Ts[n];
+    int64_t sumL = 0;
+    for (int m = 0; m < M; ++m) sumL += (L[m] = 1 + (m * 7) % 23);
+    uint32_t x = 0x9e3779b9u;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 17; x ^= x << 5; return x; };
+    std::vector<float> W((size_t)sumL * D);
+    for (float &w : W) {  // magnitudes over ten binades, both signs: sums that round at every step
+        const uint32_t r = rnd();
+        w = ldexpf(1.0f + (float)(r & 0x7fffff) / 8388608.0f, (int)((r >> 23) & 7) - 6) * ((r >> 31) ? -1.0f : 1.0f);
+    }
+    std::vector<uint8_t> F((size_t)offs[N] * D);
+    for (uint8_t &b : F) b = (rnd() & 3) == 0;
+    tsr_bank *bank = nullptr;
+    tsr_corpus *cp = nullptr;
+    int s = tsr_bank_create(ctx, W.data(), L.data(), c.data(), M, D, &bank);
+    if (s == TSR_OK) s = tsr_corpus_create(ctx, F.data(), offs.data(), N, D, &cp);
+    void *raw = nullptr;
+    const size_t n = (size_t)M * (size_t)offs[N];
+    std::vector<float> a(n), b(n);
+    if (s == TSR_OK) s = tsr_scratch(ctx, SLOT_RAW, 2 * n * sizeof(float), &raw);
+    bool same = false;
+    if (s == TSR_OK) {
+        float *r0 = (float *)raw, *r1 = r0 + n;
+        s = tsr_launch_exact_bank_mfma(ctx, bank, cp, r0);
+        if (s == TSR_OK) s = tsr_launch_exact_bank(ctx, bank, cp->d_feats, cp->P, cp->Dp, r1);
+        if (s == TSR_OK && (hipMemcpyAsync(a.data(), r0, n * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                            hipMemcpyAsync(b.data(), r1, n * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                            hipStreamSynchronize(ctx->stream) != hipSuccess))
+            s = TSR_ERR_HIP;
+        same = s == TSR_OK && memcmp(a.data(), b.data(), n * 4) == 0;
+    }
+    if (cp) tsr_corpus_destroy(cp);
+    if (bank) tsr_bank_destroy(bank);
+    if (same) {
+        ctx->exact_mfma_state = 1;
+    } else {
+        fprintf(stderr, "libtsr_hip: TSR_EXACT stays on the vector kernel on device %d: the matrix-core probe %s\n", ctx->device,
+                s == TSR_OK ? "did not reproduce the sequential f32 sums bit for bit" : "could not run");
+    }
+    return TSR_OK;  // (never an error of the caller's pass: the vector kernel is always there)
+}
+
 static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int flags,
                              float *d_all)
 {
@@ -660,13 +718,15 @@ static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp,
         if (s != TSR_ERR_UNSUPPORTED) return s;
         // geometry outside the MFMA kernel's envelope: the exact GPU kernel serves it
     }
+    if (ctx->opt_exact_kernel != TSR_EXACT_KERNEL_VALU) TSR_TRY(exact_mfma_probe(ctx));  // (first exact pass of this context only)
     void *raw = nullptr;
     TSR_TRY(tsr_scratch(ctx, SLOT_RAW, (size_t)bank->M * cp->P * sizeof(float), &raw));
     // the reference's sums bit for bit: on the matrix cores where the bank has that form (the context option
     // TSR_OPT_EXACT_KERNEL = TSR_EXACT_KERNEL_VALU keeps the vector kernel, for A/B measurements), otherwise one lane
     // per window
     int se = TSR_ERR_UNSUPPORTED;
-    if (ctx->opt_exact_kernel != TSR_EXACT_KERNEL_VALU) se = tsr_launch_exact_bank_mfma(ctx, bank, cp, (float *)raw);
+    if (ctx->opt_exact_kernel != TSR_EXACT_KERNEL_VALU && ctx->exact_mfma_state > 0)
+        se = tsr_launch_exact_bank_mfma(ctx, bank, cp, (float *)raw);
     if (se == TSR_ERR_UNSUPPORTED) {
         TSR_TRY(tsr_corpus_need_bytes(ctx, cp));
         se = tsr_launch_exact_bank(ctx, bank, cp->d_feats, cp->P, cp->Dp, (float *)raw);
@@ -1204,7 +1264,7 @@ TSR_API int tsr_threshold_edgemap(tsr_ctx *ctx, double *E, const int64_t *row_br
 TSR_API int tsr_spread_edgemap(tsr_ctx *ctx, double *E, const int64_t *row_breaks, int32_t n_blocks, int64_t T,
                                const int32_t *orientations, int32_t spread_length)
 {
-    TSR_REQUIRE(ctx && E && row_breaks && orientations, "tsr_spread_edgemap: null pointer");
+    TSR_REQUIRE(ctx && E && row_breaks, "tsr_spread_edgemap: null pointer");
     TSR_REQUIRE(n_blocks >= 0 && n_blocks <= 4096 && T >= 0, "tsr_spread_edgemap: bad geometry");
     TSR_REQUIRE(spread_length >= 1, "tsr_spread_edgemap: spread_length must be >= 1 (the reference's zero-padded copy is empty at 0)");
     for (int b = 0; b < n_blocks; ++b)
@@ -1219,9 +1279,9 @@ TSR_API int tsr_spread_edgemap(tsr_ctx *ctx, double *E, const int64_t *row_break
     TSR_TRY(tsr_scratch(ctx, SLOT_AUX2, (size_t)n_blocks * 8, &dD));
     TSR_HIP(hipMemcpyAsync(dE, E, (size_t)(rows * T) * 8, hipMemcpyHostToDevice, ctx->stream));
     TSR_HIP(hipMemcpyAsync(dB, row_breaks, (size_t)(n_blocks + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    TSR_HIP(hipMemcpyAsync(dD, orientations, (size_t)n_blocks * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (orientations) TSR_HIP(hipMemcpyAsync(dD, orientations, (size_t)n_blocks * 8, hipMemcpyHostToDevice, ctx->stream));
     TSR_TRY(tsr_launch_spread_edgemap(ctx, (const double *)dE, (double *)dO, (const int64_t *)dB, n_blocks, rows, T,
-                                      (const int32_t *)dD, spread_length));
+                                      orientations ? (const int32_t *)dD : nullptr, spread_length));
     const int64_t r0 = row_breaks[0];
     TSR_HIP(hipMemcpyAsync(E + r0 * T, (double *)dO + r0 * T, (size_t)((rows - r0) * T) * 8, hipMemcpyDeviceToHost, ctx->stream));
     TSR_HIP(hipStreamSynchronize(ctx->stream));
@@ -1372,9 +1432,15 @@ TSR_API int tsr_mixture_e_step(tsr_ctx *ctx, tsr_corpus *cp, const float *log_od
     TSR_REQUIRE(K >= 1 && K <= 65535, "tsr_mixture_e_step: K=%d out of range", K);
     const int64_t P = cp->P;
     *loglikelihood = 0.0;
-    cp->aff_K = K;
-    cp->aff_colsum.assign((size_t)K, 0.0);
-    if (P == 0) return TSR_OK;
+    // "an E-step has run" (aff_K >= 1) is committed only when everything below has succeeded: a failure in between must
+    // not leave a later M-step or download reading posteriors that were never written (or lie in the old K layout)
+    cp->aff_K = 0;
+    cp->aff_colsum.clear();
+    if (P == 0) {
+        cp->aff_K = K;
+        cp->aff_colsum.assign((size_t)K, 0.0);
+        return TSR_OK;
+    }
     TSR_HIP(hipSetDevice(ctx->device));
     if ((int64_t)P * K > cp->aff_cap) {
         TSR_HIP(hipStreamSynchronize(ctx->stream));
@@ -1398,12 +1464,15 @@ TSR_API int tsr_mixture_e_step(tsr_ctx *ctx, tsr_corpus *cp, const float *log_od
     TSR_HIP(hipMemcpyAsync(blk.data(), d_blk, blk.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     TSR_HIP(hipStreamSynchronize(ctx->stream));
     double ll = 0.0;
+    std::vector<double> colsum((size_t)K, 0.0);
     for (int b = 0; b < nb; ++b) {  // block order: reproducible
         ll += blk[(size_t)b * (K + 1)];
-        for (int k = 0; k < K; ++k) cp->aff_colsum[(size_t)k] += blk[(size_t)b * (K + 1) + 1 + k];
+        for (int k = 0; k < K; ++k) colsum[(size_t)k] += blk[(size_t)b * (K + 1) + 1 + k];
     }
-    *loglikelihood = ll;
     if (affinities) TSR_TRY(tsr_download(ctx, affinities, cp->d_aff, (size_t)P * K * sizeof(float)));
+    *loglikelihood = ll;
+    cp->aff_colsum.swap(colsum);
+    cp->aff_K = K;
     return TSR_OK;
 }
 
@@ -2030,6 +2099,7 @@ TSR_API int tsr_dist_init(tsr_ctx *ctx, const char id[128], int nranks, int rank
     TSR_HIP(hipSetDevice(ctx->device));
     uid128 u;
     memcpy(u.b, id, 128);
+    if (!ctx->d_coll) TSR_HIP(hipMalloc(&ctx->d_coll, 64));  // header + verdict flag of tsr_bank_broadcast
     TSR_NCCL(g_rccl.CommInitRank(&ctx->comm, nranks, u, rank));
     ctx->nranks = nranks;
     ctx->rank = rank;
@@ -2044,6 +2114,8 @@ TSR_API int tsr_dist_finalize(tsr_ctx *ctx)
         g_rccl.CommDestroy(ctx->comm);
     }
     ctx->comm = nullptr;
+    if (ctx->d_coll) (void)hipFree(ctx->d_coll);
+    ctx->d_coll = nullptr;
     ctx->nranks = 1;
     ctx->rank = 0;
     return TSR_OK;
@@ -2067,23 +2139,43 @@ TSR_API int tsr_bank_broadcast(tsr_ctx *ctx, tsr_bank *bank, int root)
     //    neither hang the collective nor corrupt a bank.
     int64_t hdr[4] = {bank->M, bank->D, bank->sumL, 1469598103934665603ll};
     for (int32_t l : bank->L) hdr[3] = (hdr[3] ^ (int64_t)l) * 1099511628211ll;  // FNV-1a over the lengths
+    // Every rank walks through the SAME collectives -- header broadcast, verdict all-reduce, [payload broadcast, final
+    // verdict all-reduce] -- whatever fails locally in between: a local failure (allocation, copy, rebuild) is carried
+    // into the next verdict as 0 instead of returning early, so that no rank is left waiting inside a collective the
+    // failing rank never enters and all ranks return an error together.  Only a failing RCCL call itself returns at
+    // once (the communicator is then unusable anyway).
+    int local = TSR_OK;  // first local failure
+    auto note = [&](int st) { if (local == TSR_OK && st != TSR_OK) local = st; };
+    auto hipst = [&](hipError_t e) { return e == hipSuccess ? TSR_OK : TSR_ERR_HIP; };
     void *d = nullptr;
-    TSR_TRY(tsr_scratch(ctx, SLOT_W, std::max<size_t>(bytes, 64), &d));
-    TSR_HIP(hipMemcpyAsync(d, hdr, sizeof hdr, hipMemcpyHostToDevice, ctx->stream));
-    TSR_NCCL(g_rccl.Broadcast(d, d, sizeof hdr, /*ncclChar*/ 0, root, ctx->comm, ctx->stream));
-    int64_t got[4];
-    TSR_HIP(hipMemcpyAsync(got, d, sizeof got, hipMemcpyDeviceToHost, ctx->stream));
-    TSR_HIP(hipStreamSynchronize(ctx->stream));
-    int32_t same = memcmp(got, hdr, sizeof hdr) == 0 ? 1 : 0;
-    int32_t *d_flag = reinterpret_cast<int32_t *>(static_cast<char *>(d) + 32);
-    TSR_HIP(hipMemcpyAsync(d_flag, &same, 4, hipMemcpyHostToDevice, ctx->stream));
-    TSR_NCCL(g_rccl.AllReduce(d_flag, d_flag, 1, /*ncclInt32*/ 2, /*ncclMin*/ 3, ctx->comm, ctx->stream));
+    note(tsr_scratch(ctx, SLOT_W, std::max<size_t>(bytes, 64), &d));
+    char *dc = d ? static_cast<char *>(d) : static_cast<char *>(ctx->d_coll);  // (the 64-byte buffer of tsr_dist_init)
+    int32_t *d_flag = reinterpret_cast<int32_t *>(dc + 32);
+    auto verdict = [&](int32_t mine, int32_t *all) -> int {  // MIN over ranks of `mine`
+        *all = 0;
+        note(hipst(hipMemcpyAsync(d_flag, &mine, 4, hipMemcpyHostToDevice, ctx->stream)));
+        TSR_NCCL(g_rccl.AllReduce(d_flag, d_flag, 1, /*ncclInt32*/ 2, /*ncclMin*/ 3, ctx->comm, ctx->stream));
+        int32_t v = 0;
+        note(hipst(hipMemcpyAsync(&v, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream)));
+        note(hipst(hipStreamSynchronize(ctx->stream)));
+        *all = (local == TSR_OK) ? v : 0;
+        return TSR_OK;
+    };
+    note(hipst(hipMemcpyAsync(dc, hdr, sizeof hdr, hipMemcpyHostToDevice, ctx->stream)));
+    TSR_NCCL(g_rccl.Broadcast(dc, dc, sizeof hdr, /*ncclChar*/ 0, root, ctx->comm, ctx->stream));
+    int64_t got[4] = {0, 0, 0, 0};
+    note(hipst(hipMemcpyAsync(got, dc, sizeof got, hipMemcpyDeviceToHost, ctx->stream)));
+    note(hipst(hipStreamSynchronize(ctx->stream)));
+    const int32_t same = (local == TSR_OK && d && memcmp(got, hdr, sizeof hdr) == 0) ? 1 : 0;
     int32_t all_same = 0;
-    TSR_HIP(hipMemcpyAsync(&all_same, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
-    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    TSR_TRY(verdict(same, &all_same));
     if (!all_same) {
+        if (local != TSR_OK || !d) {
+            tsr_set_error("tsr_bank_broadcast: rank %d could not stage the bank (device allocation or copy failed)", ctx->rank);
+            return local != TSR_OK ? local : TSR_ERR_HIP;
+        }
         if (same)
-            tsr_set_error("tsr_bank_broadcast: another rank's bank geometry differs from root %d's", root);
+            tsr_set_error("tsr_bank_broadcast: another rank's bank geometry differs from root %d's (or it failed locally)", root);
         else
             tsr_set_error("tsr_bank_broadcast: rank %d's bank geometry (M=%d D=%lld sumL=%lld, template lengths) "
                           "differs from root's (M=%lld D=%lld sumL=%lld)", ctx->rank, bank->M, (long long)bank->D,
@@ -2095,20 +2187,28 @@ TSR_API int tsr_bank_broadcast(tsr_ctx *ctx, tsr_bank *bank, int root)
     memcpy(host.data(), bank->L.data(), (size_t)bank->M * 4);
     memcpy(host.data() + offC, bank->c.data(), (size_t)bank->M * 8);
     memcpy(host.data() + offW, bank->W_cat.data(), nW * 4);
-    TSR_HIP(hipMemcpyAsync(d, host.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+    note(hipst(hipMemcpyAsync(d, host.data(), bytes, hipMemcpyHostToDevice, ctx->stream)));
     TSR_NCCL(g_rccl.Broadcast(d, d, bytes, /*ncclChar*/ 0, root, ctx->comm, ctx->stream));
     std::vector<char> back(bytes);
-    TSR_HIP(hipMemcpyAsync(back.data(), d, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    TSR_HIP(hipStreamSynchronize(ctx->stream));
-    if (memcmp(back.data(), bank->L.data(), (size_t)bank->M * 4) != 0) {
-        tsr_set_error("tsr_bank_broadcast: rank %d's template lengths differ from root's", ctx->rank);
-        return TSR_ERR_INVALID;
-    }
-    if (ctx->rank != root) {
+    note(hipst(hipMemcpyAsync(back.data(), d, bytes, hipMemcpyDeviceToHost, ctx->stream)));
+    note(hipst(hipStreamSynchronize(ctx->stream)));
+    bool lengths_ok = local == TSR_OK && memcmp(back.data(), bank->L.data(), (size_t)bank->M * 4) == 0;
+    if (lengths_ok && ctx->rank != root) {
         memcpy(bank->c.data(), back.data() + offC, (size_t)bank->M * 8);
         memcpy(bank->W_cat.data(), back.data() + offW, nW * 4);
         tsr_fast_bank_free(bank);  // limb tables of the old weights go first: rebuilt lazily from the new ones
-        TSR_TRY(bank_build_exact(ctx, bank));
+        note(bank_build_exact(ctx, bank));
+    }
+    // 3) final verdict: every rank holds the root's bank, or all of them say so
+    int32_t all_done = 0;
+    TSR_TRY(verdict(lengths_ok && local == TSR_OK ? 1 : 0, &all_done));
+    if (!all_done) {
+        if (local != TSR_OK) return local;  // (its own message stands)
+        if (!lengths_ok)
+            tsr_set_error("tsr_bank_broadcast: rank %d's template lengths differ from root's", ctx->rank);
+        else
+            tsr_set_error("tsr_bank_broadcast: another rank failed to take over the bank");
+        return TSR_ERR_INVALID;
     }
     return TSR_OK;
 }

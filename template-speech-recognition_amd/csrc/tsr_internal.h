@@ -55,9 +55,14 @@ struct tsr_ctx {
     tsr_devbuf scratch[8];  // per-purpose scratch slots (see tsr_scratch)
     tsr_devbuf pinned;      // page-locked host staging for large downloads (see tsr_download)
     void *comm = nullptr;   // ncclComm_t when tsr_dist_init has run
+    void *d_coll = nullptr; // 64 device bytes for the small collectives of tsr_bank_broadcast (allocated with the communicator)
     int nranks = 1, rank = 0;
     // kernel-choice options (include/tsr.h: tsr_ctx_set_option); defaults from the environment at creation only
     int opt_fast_kernel = 0, opt_exact_kernel = 0, opt_part_layout = 0, opt_xcd_map = 1;
+    // TSR_EXACT on the matrix cores rests on v_mfma_f32_16x16x4_f32 evaluating its four products as an ascending fmaf
+    // chain: 0 = not yet checked on this device, 1 = the probe matched the vector kernel bit for bit, -1 = it did not
+    // (the vector kernel serves every TSR_EXACT call of this context, said once on stderr)
+    int exact_mfma_state = 0;
 };
 
 int tsr_scratch(tsr_ctx *ctx, int slot, size_t bytes, void **out);

@@ -139,7 +139,12 @@ class BernoulliMixture:
         posteriors (one-hot on the best-scoring component with hard assignment) on the device."""
         odds, consts = self._component_tables()
         with np.errstate(divide='ignore'):
-            log_w = np.log(np.asarray(self.weights, np.float64))
+            log_w = np.log(np.asarray(self.weights, np.float64)).reshape(-1)
+        if log_w.shape[0] != self.num_mix:
+            # (a 'preset' initialisation with another number of centers changes num_mix but not the weights: the
+            # reference's np.tile(np.log(self.weights), ...) + scores then fails to broadcast, :265)
+            raise ValueError("operands could not be broadcast together with shapes (%d,%d) (%d,%d) "
+                             % (self.num_data, self.num_mix, self.num_data, log_w.shape[0]))
         total = C.c_double()
         check(lib().tsr_mixture_e_step(self._ctx._h, self._corpus._h, ptr(odds), ptr(consts), self.num_mix,
                                        ptr(np.ascontiguousarray(log_w)), int(bool(self.hard_assignment)), C.byref(total), None))

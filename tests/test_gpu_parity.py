@@ -1349,6 +1349,45 @@ def test_edges2_random_vs_oracle(mods, oracle):
     assert done > 30
 
 
+def test_g24_edges3_from_the_references_own_code(mods):
+    """g24 (tests/golden/make_golden_edges3.py: the reference's edge_signal_proc.py executed through oracle/py2ref.py):
+    spread_type='all' and the other keywords of _edge_map_threshold_segments, critical_bands of threshold_edgemap --
+    which the reference can only run into a NumPy broadcast error except for a single row block: the same exception, at
+    the same point, with the same rows already thresholded -- and return_thresholds' early return."""
+    import template_speech_rec.edge_signal_proc as esp
+    g = golden("g24_edges3_reftext")
+    for i in range(int(g["a_n"])):
+        BL, s, binary, kind = (int(x) for x in g["a%d_par" % i])
+        E = g["a%d_E_in" % i].copy()
+        r = esp._edge_map_threshold_segments(E, BL, s, threshold=.6, edge_orientations=g["a%d_orient" % i],
+                                             edge_feature_row_breaks=g["a%d_breaks" % i],
+                                             spread_type="all" if kind == 0 else "other", convert_to_binary=bool(binary))
+        assert r is None and np.array_equal(E, g["a%d_E_out" % i]), i
+    for i in range(int(g["b_n"])):
+        E = g["b%d_E_in" % i].copy()
+        err, ret = "", None
+        try:
+            ret = esp.threshold_edgemap(E, .7, g["b%d_breaks" % i], report_level=bool(g["b%d_report" % i]),
+                                        critical_bands=g["b%d_cb" % i])
+        except Exception as e:
+            err = "%s: %s" % (type(e).__name__, e)
+        assert err == str(g["b%d_err" % i]), (i, err)
+        assert np.array_equal(E, g["b%d_E_out" % i]), i
+        if ("b%d_ret_E" % i) in g:
+            nb = len(g["b%d_breaks" % i]) - 1      # (the reference's np.empty((8, bands)) is filled for the row blocks only)
+            assert np.array_equal(ret[0], g["b%d_ret_E" % i]) and np.array_equal(ret[1][:nb], g["b%d_ret_tau" % i][:nb])
+        else:
+            assert ret is None
+    E = g["c_E_in"].copy()
+    views = esp._edge_map_threshold_segments(E, 10, 1, edge_orientations=g["c_orient"], edge_feature_row_breaks=g["c_breaks"],
+                                             return_thresholds=True)
+    assert np.array_equal(np.array(views), g["c_views"]) and np.array_equal(E, g["c_E_out"])
+    E = g["c2_E_in"].copy()
+    assert esp._edge_map_threshold_segments(E, 10, 1, edge_orientations=g["c2_orient"], edge_feature_row_breaks=g["c2_breaks"],
+                                            return_thresholds=True) is None
+    assert np.array_equal(E, g["c2_E_out"])
+
+
 # ---- BASELINE config 5: the bank as a bf16 MFMA GEMM (comparison variants) ----------------------------------------
 @pytest.mark.parametrize("shape", [
     dict(N=4, T=200, F=45, E=8, M=8, L=32),                                              # config-2 shape
@@ -1388,6 +1427,38 @@ def test_bf16_unsupported_geometry_falls_back_to_exact(mods, oracle):
     a = bank.score(c["feats"], c["offsets"], flags=tsr_hip.TSR_FAST | tsr_hip.TSR_BF16)
     b = bank.score(c["feats"], c["offsets"], flags=tsr_hip.TSR_EXACT)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_exact_matrix_core_probe_and_options(mods, oracle):
+    """The first TSR_EXACT pass of a context runs the one-off probe (a fixed small bank on the matrix-core kernel and on
+    the vector kernel, raw sums compared bit for bit) before it trusts v_mfma_f32_16x16x4_f32 with the reference's
+    summation order; the verdict is readable, the option values are checked, and the environment no longer steers a
+    live context."""
+    import os
+    tsr_hip = mods[3]
+    from tsr_hip import synth
+    ctx = tsr_hip.Context(0)
+    assert ctx.get_option(tsr_hip.TSR_INFO_EXACT_MFMA) == 0
+    c = synth.corpus(9, N=3, T=[40, 22, 31], F=9, E=5, M=3, L=[7, 12, 9])
+    bank = tsr_hip.Bank(c["bank"], ctx=ctx)
+    s, a = bank.score(c["feats"], c["offsets"], flags=tsr_hip.TSR_EXACT)
+    so, ao = oracle.score_corpus(c["feats"], c["offsets"], c["bank"])
+    assert np.array_equal(s, so) and np.array_equal(a, ao)
+    assert ctx.get_option(tsr_hip.TSR_INFO_EXACT_MFMA) == 1
+    with pytest.raises(ValueError):
+        ctx.set_option(tsr_hip.TSR_OPT_FAST_KERNEL, 7)
+    with pytest.raises(ValueError):
+        ctx.set_option(tsr_hip.TSR_INFO_EXACT_MFMA, 1)
+    os.environ["TSR_EXACTK"] = "valu"               # read at context creation only
+    try:
+        assert ctx.get_option(tsr_hip.TSR_OPT_EXACT_KERNEL) == tsr_hip.TSR_OPT_AUTO
+        ctx2 = tsr_hip.Context(0)
+        assert ctx2.get_option(tsr_hip.TSR_OPT_EXACT_KERNEL) == tsr_hip.TSR_EXACT_KERNEL_VALU
+        ctx2.close()
+    finally:
+        del os.environ["TSR_EXACTK"]
+    bank.close()
+    ctx.close()
 
 
 def test_tap_pair_kernel_parity(mods, oracle):
