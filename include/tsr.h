@@ -116,6 +116,11 @@ enum { TSR_OPT_AUTO = 0,
        TSR_PART_LAYOUT_BYTES = 1, TSR_PART_LAYOUT_BITS = 2 };
 int tsr_ctx_set_option(tsr_ctx *ctx, int option, int value);
 int tsr_ctx_get_option(const tsr_ctx *ctx, int option, int *value);
+/* The large device arrays of destroyed corpora are kept in a process-wide pool (at most 2 GB) and handed to the next
+ * corpus of about the same size -- a front-end call that makes a new corpus would otherwise pay a device allocation
+ * and, when the old corpus goes, a device-wide synchronisation per array.  tsr_pool_trim returns the idle blocks to the
+ * driver. */
+int tsr_pool_trim(void);
 /* device name, CU count, HBM bytes (for bench/DESIGN reporting) */
 int tsr_device_info(tsr_ctx *ctx, char *name, int name_len, int *cus, int64_t *hbm_bytes);
 

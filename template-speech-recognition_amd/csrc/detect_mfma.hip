@@ -601,7 +601,7 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
     if (P == 0) return TSR_OK;
     // A corpus resident as bit rows (a part corpus) is read as such by the two-limb interleaved kernel (one K-slice per
     // workgroup); every other kernel reads byte rows, made from the bits on first use.
-    const bool bits = cp->d_bits != nullptr && !bf && NL == 2 && fb->KS == 1;
+    const bool bits = cp->d_bits != nullptr && !bf && NL == 2 && fb->KS == 1 && fb->NKB == cp->bit_pw && fb->n_phase == cp->bit_nph;
     if (!bits) TSR_TRY(tsr_corpus_need_bytes(ctx, cp));
     if (bf) TSR_TRY(tsr_corpus_bf16_copy(ctx, cp));
     // (bf16: the "row" is the bf16 copy's, its stride already an odd number of 16-byte slots)
@@ -664,11 +664,11 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
         a.Dp = Dp;
         a.SB = SB;
         a.src_slots = row_bytes >> 4;
-        if (bits) {  // bit rows: the phase's features are dwords [ph * k_span / 32, +NKB) of a row of Bp bytes
-            a.X = cp->d_bits;
-            a.Dp = cp->Bp;
-            a.src_slots = cp->Bp >> 2;
-            a.bit_dword0 = ph * (k_span >> 5);
+        if (bits) {  // the bit form is phase-major: this phase's plane, rows of NKB dwords
+            a.X = cp->d_bits + (size_t)ph * (size_t)cp->bit_rows * cp->bit_pw * 4;
+            a.Dp = cp->bit_pw * 4;
+            a.src_slots = cp->bit_pw;
+            a.bit_dword0 = 0;
         }
         a.tile_bytes = tile_bytes;
         a.G = fb->G;
@@ -696,7 +696,8 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
             a.all = d_all;
         }
         if (bits) {  // whole bit rows of the tiles' 32 frames: the last tile starts at a frame of the corpus
-            TSR_REQUIRE((size_t)(P + 31) * (size_t)cp->Bp <= cp->bits_alloc, "TSR_FAST: frame staging would read past the %zu-byte bit rows", cp->bits_alloc);
+            TSR_REQUIRE(P + 31 <= cp->bit_rows && (size_t)(ph + 1) * (size_t)cp->bit_rows * cp->bit_pw * 4 <= cp->bits_alloc,
+                        "TSR_FAST: frame staging would read past the %zu-byte bit form", cp->bits_alloc);
         } else {  // the staging's read-ahead stays inside the array it reads (tsr_internal.h: tsr_staging_read_end)
             const size_t end = tsr_staging_read_end(P, Dp, SB, a.src_slots, tile_bytes, flat, bf ? 0 : (size_t)ph * k_span);
             const size_t have = bf ? cp->bf16_alloc : cp->feats_alloc;

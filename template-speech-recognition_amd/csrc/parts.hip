@@ -308,7 +308,8 @@ __global__ __launch_bounds__(64 * kSpreadWaves) void spread_mask_multi_kernel(
     const int32_t *__restrict__ A, int N1, int r0, int r1, int K, int g1, int O1, int64_t P_out,
     const int32_t *__restrict__ out_src_row, const int32_t *__restrict__ out_src_lo,
     const int32_t *__restrict__ out_src_hi, const uint64_t *__restrict__ graph_masks /*[K] or null*/, int Dp_out,
-    uint8_t *__restrict__ out, uint8_t *__restrict__ out_bits /* bit rows instead of byte rows */, int Bp, int nwords)
+    uint8_t *__restrict__ out, uint8_t *__restrict__ out_bits /* the phase-major bit form instead of byte rows */, int bit_pw,
+    int bit_nph, int64_t bit_rows, int nwords, int ids8 /* A holds bytes (the MFMA coder's map) */)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sp_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -356,7 +357,8 @@ __global__ __launch_bounds__(64 * kSpreadWaves) void spread_mask_multi_kernel(
         // ---- one-hot rows of the group -> LDS; zero the frames' bit streams ---------------------------
         for (int x0 = 0; x0 < nrows; ++x0)
             for (int c = lane; c < N1; c += 64) {
-                const int p = A[(int64_t)(gmin + x0) * N1 + c];
+                const int64_t at = (int64_t)(gmin + x0) * N1 + c;
+                const int p = ids8 ? (int)reinterpret_cast<const uint8_t *>(A)[at] : A[at];
                 bits[x0 * N1 + c] = p > 0 ? 1ull << (p - 1) : 0ull;
             }
         for (int w = lane; w < kSpreadFB * nwords; w += 64) streams[w] = 0;
@@ -403,8 +405,10 @@ __global__ __launch_bounds__(64 * kSpreadWaves) void spread_mask_multi_kernel(
         // ---- bit rows: the streams as they stand (bit oj*K + k of a frame = its feature oj*K + k), whole rows ----
         if (out_bits) {
             for (int f = f_beg; f < f_end; ++f) {
-                uint32_t *row = reinterpret_cast<uint32_t *>(out_bits + (q0 + f) * Bp);
-                for (int w = lane; w < (Bp >> 2); w += 64) row[w] = streams[f * nwords + w];
+                uint32_t *o32 = reinterpret_cast<uint32_t *>(out_bits);
+                for (int ph = 0; ph < bit_nph; ++ph)  // dword w = ph * bit_pw + j of the frame -> plane ph
+                    for (int j = lane; j < bit_pw; j += 64)
+                        o32[((int64_t)ph * bit_rows + (q0 + f)) * bit_pw + j] = streams[f * nwords + ph * bit_pw + j];
             }
             __builtin_amdgcn_wave_barrier();
             continue;
@@ -462,24 +466,26 @@ int tsr_launch_out_geometry(tsr_ctx *ctx, const int64_t *d_ooff, const int32_t *
 
 // `d_out` rows need no zeroing when this returns with *wrote_all = true (mask kernel); the
 // byte-scatter kernel (K > 64) needs them zeroed and does that itself.
-static int spread_multi_words(int Dp_out, int Bp) { return std::max((Dp_out >> 5) + 3, Bp >> 2); }
-static size_t spread_multi_lds(int64_t N1, int Dp_out, int Bp)
+static int spread_multi_words(int Dp_out, int bit_words) { return std::max((Dp_out >> 5) + 3, bit_words); }
+static size_t spread_multi_lds(int64_t N1, int Dp_out, int bit_words)
 {
-    return (size_t)kSpreadWaves * (((size_t)kSpreadRows * N1 * 8 + (size_t)kSpreadFB * spread_multi_words(Dp_out, Bp) * 4 + 7) / 8 * 8);
+    return (size_t)kSpreadWaves * (((size_t)kSpreadRows * N1 * 8 + (size_t)kSpreadFB * spread_multi_words(Dp_out, bit_words) * 4 + 7) / 8 * 8);
 }
 
 // Can the dilation write the part features as bit rows (tsr_corpus.d_bits)?  Only the mask kernel that handles several
 // frames per wave does: at most 64 parts, dilation window of at most kSpreadRows source rows, its strips within 64 KB.
-bool tsr_spread_packs_bits(int64_t N1, int r0, int64_t K, int Dp_out, int Bp)
+bool tsr_spread_packs_bits(int64_t N1, int r0, int64_t K, int Dp_out, int bit_words)
 {
-    return K <= 64 && 2 * r0 + 1 <= kSpreadRows && spread_multi_lds(N1, Dp_out, Bp) <= 64 * 1024 && Dp_out % 16 == 0 && Bp % 16 == 0;
+    return K <= 64 && 2 * r0 + 1 <= kSpreadRows && spread_multi_lds(N1, Dp_out, bit_words) <= 64 * 1024 && Dp_out % 16 == 0;
 }
 
 int tsr_launch_spread_stream(tsr_ctx *ctx, const int32_t *d_A, int64_t N1, int r0, int r1, int64_t K,
                              int g0, int g1, int64_t O1, int64_t P_out, const int32_t *d_src_row,
                              const int32_t *d_src_lo, const int32_t *d_src_hi, const uint8_t *d_graph,
-                             const uint64_t *d_graph_masks, int Dp_out, uint8_t *d_out, uint8_t *d_out_bits, int Bp)
+                             const uint64_t *d_graph_masks, int Dp_out, uint8_t *d_out, uint8_t *d_out_bits, int bit_pw, int bit_nph,
+                             int64_t bit_rows, int ids8)
 {
+    const int Bp = bit_pw * bit_nph;  // dwords of a frame's bit form
     (void)g0;
     const int64_t n = P_out * O1;
     if (n <= 0) return TSR_OK;
@@ -495,9 +501,13 @@ int tsr_launch_spread_stream(tsr_ctx *ctx, const int32_t *d_A, int64_t N1, int r
         hipLaunchKernelGGL(spread_mask_multi_kernel, dim3((unsigned)((P_out + frames_per_block - 1) / frames_per_block)),
                            dim3(64 * kSpreadWaves), spread_multi_lds(N1, Dp_out, bp_eff), ctx->stream, d_A, (int)N1, r0, r1, (int)K, g1,
                            (int)O1, P_out, d_src_row, d_src_lo, d_src_hi, d_graph ? d_graph_masks : nullptr, Dp_out, d_out,
-                           d_out_bits, Bp, spread_multi_words(Dp_out, bp_eff));
+                           d_out_bits, bit_pw, bit_nph, bit_rows, spread_multi_words(Dp_out, bp_eff), ids8);
         TSR_HIP(hipGetLastError());
         return TSR_OK;
+    }
+    if (ids8) {
+        tsr_set_error("spread: byte part ids asked for a geometry the mask kernel does not cover");
+        return TSR_ERR_UNSUPPORTED;
     }
     if (K <= 64 && lds <= 48 * 1024 && Dp_out % 16 == 0) {
         hipLaunchKernelGGL(spread_mask_kernel, dim3((unsigned)((P_out + kSpreadWaves - 1) / kSpreadWaves)),

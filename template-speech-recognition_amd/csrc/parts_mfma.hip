@@ -67,6 +67,7 @@ struct PmArgs {
     int n_inv;                 // empty part slots (incl. the row of ones)
     int *work;                 // [0] chunk counter, [1] list length
     int32_t *argmax;           // [P][N1]
+    int ids8;                  // the map is written as bytes (K <= 63: the dilation kernel of the corpus chain reads them so)
     uint32_t *list;            // [n][2]: location, full (slot 0 of code_parts_fast in play)
 };
 
@@ -204,7 +205,13 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
                 a.list[(size_t)slot * 2] = (uint32_t)loc;
                 a.list[(size_t)slot * 2 + 1] = full ? 1u : 0u;
             }
-            if (live && half == 0 && !flag) a.argmax[loc] = coded ? (mbest & 63) + 1 : 0;
+            if (live && half == 0 && !flag) {
+                const int id = coded ? (mbest & 63) + 1 : 0;
+                if (a.ids8)
+                    reinterpret_cast<uint8_t *>(a.argmax)[loc] = (uint8_t)id;
+                else
+                    a.argmax[loc] = id;
+            }
         }
     }
 }
@@ -222,7 +229,7 @@ constexpr int kRcBins = 32;  // P0 * P1 <= 2 * (16 K-groups)
 
 __global__ __launch_bounds__(64 * kRcWaves) void code_parts_recheck_kernel(
     const uint8_t *__restrict__ X, int Dp, int P0, int P1, int N1, const double *__restrict__ tab /*[Q][K][2]*/,
-    int K, int fast, const uint32_t *__restrict__ list, const int *__restrict__ work, int32_t *__restrict__ argmax)
+    int K, int fast, const uint32_t *__restrict__ list, const int *__restrict__ work, int32_t *__restrict__ argmax, int ids8)
 {
     static_assert(kRcEnt == 4, "the bin word below holds 4 entries");
     __shared__ __attribute__((aligned(4))) uint8_t xbits[kRcWaves][kRcBins][kRcEnt];  // one byte = the 8 edge bits of one bin of one entry's patch
@@ -280,7 +287,12 @@ __global__ __launch_bounds__(64 * kRcWaves) void code_parts_recheck_kernel(
                 for (int k = 0; k < K; ++k) slot0 += __shfl(acc[e], k) - 1.0;
                 if (!(bv > slot0)) res = 0;
             }
-            if (lane == 0) argmax[list[(size_t)(e0 + e) * 2]] = res;
+            if (lane == 0) {
+                if (ids8)
+                    reinterpret_cast<uint8_t *>(argmax)[list[(size_t)(e0 + e) * 2]] = (uint8_t)res;
+                else
+                    argmax[list[(size_t)(e0 + e) * 2]] = res;
+            }
         }
         __builtin_amdgcn_wave_barrier();  // xbits is rewritten by the next group
     }
@@ -420,7 +432,7 @@ int tsr_parts_mfma_prepare(tsr_ctx *ctx, tsr_parts *p, const double *lp, const d
 // d_list must hold 8 bytes per location, d_work two ints.
 int tsr_launch_code_parts_mfma(tsr_ctx *ctx, const tsr_parts *p, const uint8_t *d_X, int64_t P, int64_t X1,
                                int Dp, const int32_t *d_utt_end, int threshold, int fast, int32_t *d_argmax,
-                               uint32_t *d_list, int *d_work)
+                               uint32_t *d_list, int *d_work, int ids8)
 {
     if (!p->mfma_ok) return TSR_ERR_UNSUPPORTED;
     const int64_t N1 = X1 - p->P1 + 1;
@@ -461,6 +473,7 @@ int tsr_launch_code_parts_mfma(tsr_ctx *ctx, const tsr_parts *p, const uint8_t *
     a.n_inv = p->pm_n_inv;
     a.work = d_work;
     a.argmax = d_argmax;
+    a.ids8 = ids8;
     a.list = d_list;
     int s = TSR_OK;
     switch (p->nkb) {
@@ -477,7 +490,7 @@ int tsr_launch_code_parts_mfma(tsr_ctx *ctx, const tsr_parts *p, const uint8_t *
     TSR_TRY(s);
     hipLaunchKernelGGL(code_parts_recheck_kernel, dim3((unsigned)(8 * std::max(ctx->cus, 1))), dim3(64 * kRcWaves), 0, ctx->stream,
                        d_X, Dp, (int)p->P0, (int)p->P1, (int)N1, p->d_tab, (int)p->K, fast ? 1 : 0,
-                       (const uint32_t *)d_list, (const int *)d_work, d_argmax);
+                       (const uint32_t *)d_list, (const int *)d_work, d_argmax, ids8);
     TSR_HIP(hipGetLastError());
     return TSR_OK;
 }

@@ -11,6 +11,9 @@
 
 #include "tsr_internal.h"
 
+#include <mutex>
+#include <unordered_map>
+
 // ---- errors ---------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
@@ -246,6 +249,104 @@ void dev_free(void *p)
     if (p) (void)hipFree(p);
 }
 
+// ---- a small pool for the large arrays of corpora -------------------------------------------------------------
+// tsr_corpus_part_features / tsr_edge_corpus_create make a new corpus per call; its feature form, result arrays and
+// utterance tables are hipMalloc'ed, and a corpus that goes away hipFree's them (each a device-wide synchronisation
+// and, for the next call, a fresh allocation: ~0.2-0.4 ms per call at config 3, as much as the kernels it feeds).
+// Blocks of destroyed corpora are kept here instead (process-wide: a corpus may outlive its context) and handed to the
+// next corpus that asks for about the same size.  Bounded (kPoolMaxBytes); tsr_pool_trim() gives everything back.
+namespace {
+struct PoolBlock {
+    void *p;
+    size_t bytes;
+    int device;
+};
+struct DevPool {
+    std::mutex mu;
+    std::vector<PoolBlock> idle;
+    std::unordered_map<void *, std::pair<size_t, int>> live;  // blocks handed out: size, device
+    size_t held = 0;
+};
+DevPool &pool()
+{
+    static DevPool *g = new DevPool;  // (never destroyed: no teardown-order problems at process exit)
+    return *g;
+}
+constexpr size_t kPoolMaxBytes = (size_t)2 << 30, kPoolMinBlock = (size_t)64 << 10;
+
+hipError_t pool_malloc(int device, void **out, size_t bytes)
+{
+    bytes = std::max<size_t>(bytes, 16);
+    DevPool &pl = pool();
+    if (bytes >= kPoolMinBlock) {
+        std::lock_guard<std::mutex> g(pl.mu);
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < pl.idle.size(); ++i) {
+            const PoolBlock &b = pl.idle[i];
+            if (b.device == device && b.bytes >= bytes && b.bytes <= bytes + bytes / 4 && (best == (size_t)-1 || b.bytes < pl.idle[best].bytes)) best = i;
+        }
+        if (best != (size_t)-1) {
+            const PoolBlock b = pl.idle[best];
+            pl.idle.erase(pl.idle.begin() + (long)best);
+            pl.held -= b.bytes;
+            pl.live[b.p] = {b.bytes, b.device};
+            *out = b.p;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) {  // give the pool's idle blocks back and try once more
+        tsr_pool_trim();
+        e = hipMalloc(out, bytes);
+    }
+    if (e == hipSuccess && bytes >= kPoolMinBlock) {
+        std::lock_guard<std::mutex> g(pl.mu);
+        pl.live[*out] = {bytes, device};
+    }
+    return e;
+}
+
+void pool_free(void *p)  // (the caller has synchronised the device: nothing in flight uses the block)
+{
+    if (!p) return;
+    DevPool &pl = pool();
+    {
+        std::lock_guard<std::mutex> g(pl.mu);
+        auto it = pl.live.find(p);
+        if (it != pl.live.end()) {
+            const size_t bytes = it->second.first;
+            const int device = it->second.second;
+            pl.live.erase(it);
+            if (pl.held + bytes <= kPoolMaxBytes) {
+                pl.idle.push_back({p, bytes, device});
+                pl.held += bytes;
+                return;
+            }
+        }
+    }
+    (void)hipFree(p);
+}
+}  // namespace
+
+TSR_API int tsr_pool_trim(void)
+{
+    DevPool &pl = pool();
+    std::vector<PoolBlock> idle;
+    {
+        std::lock_guard<std::mutex> g(pl.mu);
+        idle.swap(pl.idle);
+        pl.held = 0;
+    }
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (const PoolBlock &b : idle) {
+        (void)hipSetDevice(b.device);
+        (void)hipFree(b.p);
+    }
+    (void)hipSetDevice(cur);
+    return TSR_OK;
+}
+
 enum { SLOT_RAW = 0, SLOT_IN = 1, SLOT_W = 2, SLOT_OUT = 3, SLOT_AUX = 4, SLOT_AUX2 = 5, SLOT_LIST = 6, SLOT_CNT = 7 };
 
 }  // namespace
@@ -450,7 +551,7 @@ TSR_API int tsr_corpus_destroy(tsr_corpus *cp);
 static int corpus_alloc_bytes(tsr_ctx *ctx, tsr_corpus *cp)
 {
     const size_t body = (size_t)cp->P * cp->Dp, slack = (size_t)48 * cp->Dp + 8192;
-    if (hipMalloc(reinterpret_cast<void **>(&cp->d_feats), body + slack) != hipSuccess ||
+    if (pool_malloc(cp->device, reinterpret_cast<void **>(&cp->d_feats), body + slack) != hipSuccess ||
         hipMemsetAsync(cp->d_feats + body, 0, slack, ctx->stream) != hipSuccess) {
         tsr_set_error("tsr_corpus_create: cannot allocate %zu bytes of device memory", body + slack);
         return TSR_ERR_HIP;
@@ -461,20 +562,25 @@ static int corpus_alloc_bytes(tsr_ctx *ctx, tsr_corpus *cp)
 
 int tsr_corpus_alloc_bits(tsr_ctx *ctx, tsr_corpus *cp)
 {
-    cp->Bp = (int)(((cp->D + 7) / 8 + 15) / 16 * 16);
-    const size_t body = (size_t)cp->P * cp->Bp, slack = (size_t)48 * cp->Bp + 8192;
-    if (hipMalloc(reinterpret_cast<void **>(&cp->d_bits), body + slack) != hipSuccess ||
-        hipMemsetAsync(cp->d_bits + body, 0, slack, ctx->stream) != hipSuccess) {
-        tsr_set_error("tsr_corpus_part_features: cannot allocate %zu bytes of device memory", body + slack);
+    tsr_bit_geometry(cp->D, &cp->bit_pw, &cp->bit_nph);
+    cp->bit_rows = cp->P + 48;  // (tiles of the bank pass read whole 32-frame tiles: the last one starts at a frame of the corpus)
+    const size_t plane = (size_t)cp->bit_rows * cp->bit_pw * 4, total = plane * cp->bit_nph + 256;
+    if (pool_malloc(cp->device, reinterpret_cast<void **>(&cp->d_bits), total) != hipSuccess) {
+        tsr_set_error("tsr_corpus_part_features: cannot allocate %zu bytes of device memory", total);
         return TSR_ERR_HIP;
     }
-    cp->bits_alloc = body + slack;
+    for (int ph = 0; ph < cp->bit_nph; ++ph)  // the read-ahead rows behind the frames of every plane
+        if (hipMemsetAsync(cp->d_bits + (size_t)ph * plane + (size_t)cp->P * cp->bit_pw * 4, 0, (size_t)48 * cp->bit_pw * 4, ctx->stream) != hipSuccess) {
+            tsr_set_error("tsr_corpus_part_features: device memset failed");
+            return TSR_ERR_HIP;
+        }
+    cp->bits_alloc = total;
     return TSR_OK;
 }
 
 namespace {
 // bit rows [P][Bp] -> byte rows [P][Dp] in {0,1}; one lane per 16 output bytes, bytes past D are zero
-__global__ __launch_bounds__(256) void corpus_unpack_bits_kernel(const uint8_t *__restrict__ bits, int64_t P, int Bp, int D, int Dp,
+__global__ __launch_bounds__(256) void corpus_unpack_bits_kernel(const uint8_t *__restrict__ bits, int64_t P, int pw, int64_t rows, int D, int Dp,
                                                                  uint8_t *__restrict__ out)
 {
     const int per_row = Dp >> 4;
@@ -482,7 +588,8 @@ __global__ __launch_bounds__(256) void corpus_unpack_bits_kernel(const uint8_t *
     if (i >= P * per_row) return;
     const int64_t p = i / per_row;
     const int c = (int)(i - p * per_row);
-    unsigned b = reinterpret_cast<const uint16_t *>(bits + p * Bp)[c];
+    const int dw = c >> 1, ph = dw / pw, j = dw - ph * pw;  // dword dw of the frame: plane ph, dword j of its row there
+    unsigned b = reinterpret_cast<const uint16_t *>(bits)[(((int64_t)ph * rows + p) * pw + j) * 2 + (c & 1)];
     const int left = D - 16 * c;  // features of this chunk that exist
     if (left < 16) b &= (1u << (left > 0 ? left : 0)) - 1u;
     unsigned w[4];
@@ -501,13 +608,33 @@ int tsr_corpus_need_bytes(tsr_ctx *ctx, const tsr_corpus *cpc)
     TSR_TRY(corpus_alloc_bytes(ctx, cp));
     const int64_t n = cp->P * (cp->Dp >> 4);
     hipLaunchKernelGGL(corpus_unpack_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, cp->d_bits, cp->P,
-                       cp->Bp, (int)cp->D, cp->Dp, cp->d_feats);
+                       cp->bit_pw, cp->bit_rows, (int)cp->D, cp->Dp, cp->d_feats);
     TSR_HIP(hipGetLastError());
     return TSR_OK;
 }
 
+namespace {
+// frame p -> [first frame, end frame) of the utterance that holds it (the last n with offs[n] <= p)
+__global__ __launch_bounds__(256) void utt_tables_kernel(const int64_t *__restrict__ offs, int64_t N, int64_t P, int32_t *__restrict__ beg,
+                                                         int32_t *__restrict__ end)
+{
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    int64_t lo = 0, hi = N;  // invariant: offs[lo] <= p < offs[hi]  (empty utterances share an offset: the last one wins, its end > p)
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (offs[mid] <= p)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    beg[p] = (int32_t)offs[lo];
+    end[p] = (int32_t)offs[lo + 1];
+}
+}  // namespace
+
 // Allocate a corpus (resident feature rows zero-initialised only in the slack, utterance tables
-// uploaded, result arrays allocated) without any feature data.
+// made on the device, result arrays allocated) without any feature data.
 int tsr_corpus_create_empty(tsr_ctx *ctx, const int64_t *frame_offsets, int64_t N, int64_t D,
                             tsr_corpus **out, bool alloc_bytes)
 {
@@ -528,20 +655,28 @@ int tsr_corpus_create_empty(tsr_ctx *ctx, const int64_t *frame_offsets, int64_t 
     cp->D = D;
     cp->P = P;
     cp->offsets.assign(frame_offsets, frame_offsets + N + 1);
-    std::vector<int32_t> ub((size_t)P), ue((size_t)P);
-    for (int64_t n = 0; n < N; ++n)
-        for (int64_t p = frame_offsets[n]; p < frame_offsets[n + 1]; ++p) {
-            ub[(size_t)p] = (int32_t)frame_offsets[n];
-            ue[(size_t)p] = (int32_t)frame_offsets[n + 1];
-        }
     // resident form: 0/1 bytes, rows of Dp = round_up(D,16) bytes, zeroed slack behind the
     // last row (tiles of the scoring kernels may read, never use, up to ~48 rows past it)
     cp->Dp = (int)((D + 15) / 16 * 16);
     int s = alloc_bytes ? corpus_alloc_bytes(ctx, cp) : TSR_OK;
-    if (s == TSR_OK) s = dev_upload(ctx, &cp->d_utt_beg, ub.data(), ub.size());
-    if (s == TSR_OK) s = dev_upload(ctx, &cp->d_utt_end, ue.data(), ue.size(), 256 * sizeof(int32_t));  // zeroed slack: tiles read past P
-    if (s == TSR_OK) s = dev_upload<float>(ctx, &cp->d_scores, nullptr, 0, (size_t)P * 4);
-    if (s == TSR_OK) s = dev_upload<int32_t>(ctx, &cp->d_ids, nullptr, 0, (size_t)P * 4);
+    // per-frame utterance tables (first frame / end frame of the utterance holding p; 256 zero ints behind utt_end: tiles
+    // read past P), made on the device from the N + 1 offsets; scores and ids are written before they are read
+    auto grab = [&](void **q, size_t bytes) { return pool_malloc(cp->device, q, bytes) == hipSuccess ? TSR_OK : TSR_ERR_HIP; };
+    void *d_off = nullptr;
+    if (s == TSR_OK) s = grab(reinterpret_cast<void **>(&cp->d_utt_beg), (size_t)std::max<int64_t>(P, 1) * 4);
+    if (s == TSR_OK) s = grab(reinterpret_cast<void **>(&cp->d_utt_end), (size_t)(P + 256) * 4);
+    if (s == TSR_OK) s = grab(reinterpret_cast<void **>(&cp->d_scores), (size_t)std::max<int64_t>(P, 1) * 4);
+    if (s == TSR_OK) s = grab(reinterpret_cast<void **>(&cp->d_ids), (size_t)std::max<int64_t>(P, 1) * 4);
+    if (s == TSR_OK) s = tsr_scratch(ctx, SLOT_CNT, (size_t)(N + 1) * 8 + 64, &d_off);
+    if (s == TSR_OK && (hipMemcpyAsync(d_off, frame_offsets, (size_t)(N + 1) * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                        hipMemsetAsync(cp->d_utt_end + P, 0, 256 * 4, ctx->stream) != hipSuccess))
+        s = TSR_ERR_HIP;
+    if (s == TSR_OK && P > 0) {
+        hipLaunchKernelGGL(utt_tables_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, (const int64_t *)d_off, N, P,
+                           cp->d_utt_beg, cp->d_utt_end);
+        if (hipGetLastError() != hipSuccess) s = TSR_ERR_HIP;
+    }
+    if (s == TSR_ERR_HIP) tsr_set_error("tsr_corpus_create: cannot allocate or fill the corpus tables");
     if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {
         tsr_set_error("tsr_corpus_create: upload failed");
         s = TSR_ERR_HIP;
@@ -589,12 +724,12 @@ TSR_API int tsr_corpus_destroy(tsr_corpus *cp)
     // shutdown destroys objects in arbitrary order); hipFree needs only the device.
     (void)hipSetDevice(cp->device);
     (void)hipDeviceSynchronize();
-    dev_free(cp->d_feats);
-    dev_free(cp->d_bits);
-    dev_free(cp->d_utt_beg);
-    dev_free(cp->d_utt_end);
-    dev_free(cp->d_scores);
-    dev_free(cp->d_ids);
+    pool_free(cp->d_feats);
+    pool_free(cp->d_bits);
+    pool_free(cp->d_utt_beg);
+    pool_free(cp->d_utt_end);
+    pool_free(cp->d_scores);
+    pool_free(cp->d_ids);
     dev_free(cp->d_plan);
     dev_free(cp->d_aff);
     dev_free(cp->d_feats_bf16);
@@ -1896,8 +2031,10 @@ TSR_API int tsr_corpus_part_features(tsr_ctx *ctx, const tsr_parts *parts, const
     // the output corpus object (features are produced on the device, not uploaded)
     // Resident form of the result: bit rows (an eighth of the bytes to write here and to read in the bank pass) whenever
     // the dilation kernel can write them; byte rows are made from them on first use by anything that wants bytes.
-    const int Dp_new = (int)((O1 * K + 15) / 16 * 16), Bp_new = (int)(((O1 * K + 7) / 8 + 15) / 16 * 16);
-    const bool want_bits = ctx->opt_part_layout != TSR_PART_LAYOUT_BYTES && tsr_spread_packs_bits(N1, r0, K, Dp_new, Bp_new);
+    const int Dp_new = (int)((O1 * K + 15) / 16 * 16);
+    int pw_new = 0, nph_new = 0;
+    tsr_bit_geometry(O1 * K, &pw_new, &nph_new);
+    const bool want_bits = ctx->opt_part_layout != TSR_PART_LAYOUT_BYTES && tsr_spread_packs_bits(N1, r0, K, Dp_new, pw_new * nph_new);
     TSR_REQUIRE(want_bits || ctx->opt_part_layout != TSR_PART_LAYOUT_BITS,
                 "tsr_corpus_part_features: TSR_PART_LAYOUT_BITS, but the dilation cannot write bit rows for K=%lld, r0=%d", (long long)K, r0);
     TSR_TRY(tsr_corpus_need_bytes(ctx, edges));
@@ -1938,7 +2075,9 @@ TSR_API int tsr_corpus_part_features(tsr_ctx *ctx, const tsr_parts *parts, const
             s = TSR_ERR_HIP;
         dGm = (uint8_t *)dG + goff;
     }
-    // part ids: the MFMA coder when the tables fit it, else (or on request) the VALU kernel
+    // part ids: the MFMA coder when the tables fit it, else (or on request) the VALU kernel.  In the chain MFMA coder ->
+    // mask dilation the id map is BYTES (K <= 63; 8 instead of 33 MB at config 3, written once and read once)
+    const int ids8 = tsr_spread_packs_bits(N1, r0, K, Dp_new, want_bits ? pw_new * nph_new : 0) ? 1 : 0;
     bool used_mfma = false;
     void *dWork = nullptr;
     if (s == TSR_OK && edges->P > 0) {
@@ -1949,7 +2088,7 @@ TSR_API int tsr_corpus_part_features(tsr_ctx *ctx, const tsr_parts *parts, const
             if (sm == TSR_OK) sm = tsr_scratch(ctx, SLOT_CNT, 64, &dWork);
             if (sm == TSR_OK)
                 sm = tsr_launch_code_parts_mfma(ctx, parts, edges->d_feats, edges->P, X1, edges->Dp, edges->d_utt_end,
-                                                threshold, fast, (int32_t *)dA, (uint32_t *)dList, (int *)dWork);
+                                                threshold, fast, (int32_t *)dA, (uint32_t *)dList, (int *)dWork, ids8);
             used_mfma = sm == TSR_OK;
         }
         if (sm == TSR_ERR_UNSUPPORTED && parts->mode == TSR_PARTS_MFMA) {
@@ -1965,7 +2104,8 @@ TSR_API int tsr_corpus_part_features(tsr_ctx *ctx, const tsr_parts *parts, const
     }
     if (s == TSR_OK && P_out > 0)
         s = tsr_launch_spread_stream(ctx, (const int32_t *)dA, N1, r0, r1, K, g0, g1, O1, P_out, d_src_row,
-                                     d_src_lo, d_src_hi, (const uint8_t *)dG, (const uint64_t *)dGm, cp->Dp, cp->d_feats, cp->d_bits, cp->Bp);
+                                     d_src_lo, d_src_hi, (const uint8_t *)dG, (const uint64_t *)dGm, cp->Dp, cp->d_feats, cp->d_bits, cp->bit_pw,
+                                     cp->bit_nph, cp->bit_rows, used_mfma ? ids8 : 0);
     int work_host[2] = {0, -1};
     if (s == TSR_OK && used_mfma &&
         hipMemcpyAsync(work_host, dWork, sizeof(work_host), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)

@@ -139,11 +139,17 @@ struct tsr_corpus {
     uint16_t *d_feats_bf16 = nullptr; // bf16 copy of the frames (rows of bf16_stride bytes), built on first use by TSR_BF16
     int bf16_stride = 0;
     size_t feats_alloc = 0, bf16_alloc = 0;  // bytes allocated behind d_feats / d_feats_bf16 (frames + zeroed slack)
-    // Bit rows [P][Bp]: bit d of a frame's row (little-endian dwords) = its feature d; Bp = round_up(ceil(D/8), 16).
-    // The resident form tsr_corpus_part_features leaves behind (an eighth of the byte form).  A corpus that has
-    // them may lack d_feats until something needs byte rows (tsr_corpus_need_bytes).
+    // Bit form of the features, the resident form tsr_corpus_part_features leaves behind (an eighth of the byte form):
+    // bit (d mod 32) of dword d / 32 of a frame = its feature d, and the dwords of a frame are laid out PHASE-MAJOR --
+    // [bit_nph phases][bit_rows frames][bit_pw dwords], dword w of frame p at ((w / bit_pw) * bit_rows + p) * bit_pw +
+    // w % bit_pw -- where a phase is the feature range one pass of the two-limb bank kernel holds in registers
+    // (tsr_bit_geometry: a pure function of D).  A K-phase of the bank pass then reads one contiguous plane, 32 frames
+    // of a tile = 32 * bit_pw consecutive dwords, and every byte of the form leaves HBM once per bank pass (row-major
+    // bit rows made every phase pull every 128-byte line of the whole form).  bit_rows = P + 48 (read-ahead of the last
+    // tile).  A corpus that has this form may lack d_feats until something needs byte rows (tsr_corpus_need_bytes).
     uint8_t *d_bits = nullptr;
-    int Bp = 0;
+    int bit_pw = 0, bit_nph = 0;
+    int64_t bit_rows = 0;
     size_t bits_alloc = 0;
     // Bernoulli mixture: the posterior component probabilities the latest E-step left on the device
     float *d_aff = nullptr;          // [P][aff_K]
@@ -182,6 +188,16 @@ static inline size_t tsr_staging_read_end(int64_t P, int Dp, int SB, int src_slo
     if (flat) return first + (size_t)tile_bytes;
     const size_t rows = ((size_t)tile_bytes / 16 + (size_t)(SB >> 4) - 1) / (size_t)(SB >> 4);
     return first + (rows - 1) * (size_t)Dp + (size_t)src_slots * 16;
+}
+
+// K-blocks (of 32 features) a wave of the interleaved bank kernel keeps in registers (detect_mfma_kernel.inc: kMaxNKB)
+#define TSR_FAST_MAX_NKB 12
+// Phases and dwords per phase of the bit form of D features: what tsr_fast_bank_build derives from D for two limbs.
+static inline void tsr_bit_geometry(int64_t D, int *pw, int *nph)
+{
+    const int nkb_total = (int)((D + 31) / 32);
+    *nph = (nkb_total + TSR_FAST_MAX_NKB - 1) / TSR_FAST_MAX_NKB;
+    *pw = (nkb_total + *nph - 1) / *nph;
 }
 
 // Byte rows of a corpus that so far holds only bit rows (unpacked on the device, kept); no-op otherwise.
@@ -249,7 +265,7 @@ int tsr_parts_mfma_prepare(tsr_ctx *ctx, tsr_parts *p, const double *lp, const d
 void tsr_parts_mfma_free(tsr_parts *p);
 int tsr_launch_code_parts_mfma(tsr_ctx *ctx, const tsr_parts *p, const uint8_t *d_X, int64_t P, int64_t X1,
                                int Dp, const int32_t *d_utt_end, int threshold, int fast, int32_t *d_argmax,
-                               uint32_t *d_list, int *d_work);
+                               uint32_t *d_list, int *d_work, int ids8 = 0);
 // detect_mfma.hip
 int tsr_fast_bank_build(tsr_ctx *ctx, tsr_bank *bank, int kind);  // kind: index into tsr_bank::fast
 int tsr_corpus_bf16_copy(tsr_ctx *ctx, struct tsr_corpus *cp);
@@ -268,8 +284,9 @@ int tsr_launch_spread_graph(tsr_ctx *ctx, uint8_t *d_X, int64_t n_loc, int64_t K
 int tsr_launch_code_parts_stream(tsr_ctx *ctx, const tsr_parts *parts, const uint8_t *d_X, int64_t P,
                                  int64_t X1, int Dp, const int32_t *d_utt_end, int threshold, int fast,
                                  int32_t *d_argmax);
-bool tsr_spread_packs_bits(int64_t N1, int r0, int64_t K, int Dp_out, int Bp);
+bool tsr_spread_packs_bits(int64_t N1, int r0, int64_t K, int Dp_out, int bit_words /* dwords of a frame's bit form; 0: bytes */);
 int tsr_launch_spread_stream(tsr_ctx *ctx, const int32_t *d_A, int64_t N1, int r0, int r1, int64_t K,
                              int g0, int g1, int64_t O1, int64_t P_out, const int32_t *d_src_row,
                              const int32_t *d_src_lo, const int32_t *d_src_hi, const uint8_t *d_graph,
-                             const uint64_t *d_graph_masks, int Dp_out, uint8_t *d_out, uint8_t *d_out_bits = nullptr, int Bp = 0);
+                             const uint64_t *d_graph_masks, int Dp_out, uint8_t *d_out, uint8_t *d_out_bits = nullptr, int bit_pw = 0,
+                             int bit_nph = 0, int64_t bit_rows = 0, int ids8 = 0);

@@ -9,4 +9,4 @@ from ._lib import (TSR_EXACT, TSR_FAST, TSR_W24, TSR_BF16, TSR_PARTS_AUTO, TSR_P
                    TSR_FAST_KERNEL_TAP2, TSR_FAST_KERNEL_INTERLEAVED, TSR_EXACT_KERNEL_VALU, TSR_EXACT_KERNEL_MFMA,
                    TSR_PART_LAYOUT_BYTES, TSR_PART_LAYOUT_BITS, TSR_INFO_EXACT_MFMA, TsrError, LIB_PATH)
 from .api import (Bank, Context, Corpus, Parts, default_ctx, detect_clusters, device_count,  # noqa: F401
-                  pack_filters, peaks, unique_id, window_peak_max)
+                  pack_filters, peaks, pool_trim, unique_id, window_peak_max)

@@ -24,6 +24,7 @@ _pp = C.POINTER(C.c_void_p)
 # name -> argtypes, exactly the declarations of include/tsr.h (restype is int unless noted)
 SIGNATURES = {
     "tsr_version": [],
+    "tsr_pool_trim": [],
     "tsr_device_count": [C.POINTER(_int)],
     "tsr_ctx_create": [_int, _pp],
     "tsr_ctx_destroy": [_p],

@@ -94,6 +94,11 @@ def default_ctx():
     return _default_ctx
 
 
+def pool_trim():
+    """Give the idle device blocks of destroyed corpora back to the driver (tsr_pool_trim)."""
+    check(lib().tsr_pool_trim())
+
+
 def device_count():
     n = C.c_int()
     check(lib().tsr_device_count(C.byref(n)))
