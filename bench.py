@@ -260,6 +260,30 @@ def config3(ctx, corpus, flags, layout=None):
                     "output corpus), bank = one TSR_FAST pass over the resident part corpus"}
 
 
+def long_corpus(ctx, corpus, bank, flags, times=10):
+    """The same kernel on `times` x the utterances in ONE launch (10 000 utterances of config 2's shape): the
+    per-workgroup prologue (bank -> registers) and the launch itself are paid once per `times` corpora -- the asymptote
+    of the launch-per-1000-utterances figure in `value`.  Never part of `value`."""
+    feats = np.concatenate([corpus["feats"]] * times)
+    offs = np.concatenate([corpus["offsets"][:-1] + k * int(corpus["offsets"][-1]) for k in range(times)] +
+                          [np.array([times * int(corpus["offsets"][-1])], np.int64)])
+    big = [tsr_hip.Corpus(feats, offs, ctx=ctx) for _ in range(2)]   # two copies: 1.5 GB, streamed from HBM alternately
+    del feats
+    for c in big:
+        c.score(bank, flags)
+    ms, _ = time_launches(ctx, big, bank, flags, 5)
+    frames = int(offs[-1])
+    s0, _ = big[0].download()
+    same = bool(np.array_equal(s0[:int(corpus["offsets"][-1])], s0[-int(corpus["offsets"][-1]):]))   # first and last copy of the corpus
+    for c in big:
+        c.close()
+    return {"utterances_per_launch": (len(offs) - 1), "frames_per_launch": frames, "kernel_ms_per_launch": ms,
+            "kernel_us_per_1000_utterances": ms * 1e3 / times, "frames_per_s": frames / (ms * 1e-3),
+            "alg_tflops": ALG_FLOPS * times / (ms * 1e-3) / 1e12, "frac_of_int8_peak": ALG_FLOPS * times / (ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
+            "hbm_gbs_alg": ALG_BYTES_PER_FRAME * frames / (ms * 1e-3) / 1e9, "first_and_last_copy_score_alike": same,
+            "what": "config 2's corpus %d times over in one launch: prologue and launch amortised %dx" % (times, times)}
+
+
 def time_launches(ctx, replicas, bank, flags, steps):
     """`steps` passes over the replica list -> (ms per launch by hipEvents on the launch stream, wall s)."""
     ctx.sync()
@@ -553,7 +577,11 @@ def main():
         out["modes"] = modes
     if rank == 0:
         if world == 1 and not args.no_modes:
+            for c in replicas[1:]:      # (the replica list has done its work: make room)
+                c.close()
             out["configs"] = {"config3": config3(ctx, corpus, flags)}
+            if args.mode == "fast":
+                out["configs"]["config2_x10_one_launch"] = long_corpus(ctx, corpus, bank, flags)
         if world == 1 and args.extras:
             out["extras"] = extras(ctx, corpus, bank, flags)
             out["extras"]["cpu_allcores"] = allcores

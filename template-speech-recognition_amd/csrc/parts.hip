@@ -406,9 +406,10 @@ __global__ __launch_bounds__(64 * kSpreadWaves) void spread_mask_multi_kernel(
         if (out_bits) {
             for (int f = f_beg; f < f_end; ++f) {
                 uint32_t *o32 = reinterpret_cast<uint32_t *>(out_bits);
-                for (int ph = 0; ph < bit_nph; ++ph)  // dword w = ph * bit_pw + j of the frame -> plane ph
-                    for (int j = lane; j < bit_pw; j += 64)
-                        o32[((int64_t)ph * bit_rows + (q0 + f)) * bit_pw + j] = streams[f * nwords + ph * bit_pw + j];
+                for (int w = lane; w < bit_nph * bit_pw; w += 64) {  // dword w = ph * bit_pw + j of the frame -> plane ph
+                    const int ph = w / bit_pw, j = w - ph * bit_pw;
+                    o32[((int64_t)ph * bit_rows + (q0 + f)) * bit_pw + j] = streams[f * nwords + w];
+                }
             }
             __builtin_amdgcn_wave_barrier();
             continue;

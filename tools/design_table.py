@@ -1,0 +1,125 @@
+"""The kernel summary table of DESIGN.md section 4, generated from the evidence files under profiles/ so that the prose
+cannot drift from them (round-2 review, item 7/9):
+    python tools/design_table.py [round=r03] > /tmp/table.md        # or: --write to splice it into DESIGN.md
+Every cell names the file it comes from; a missing file yields "n/a" (never a remembered number)."""
+import csv, json, os, re, sys
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+R = next((a for a in sys.argv[1:] if re.fullmatch(r"r\d\d", a)), "r03")
+P = lambda name: os.path.join(ROOT, "profiles", "%s_%s" % (R, name))
+
+
+def kavg(csv_name, needle):
+    """(average us, calls) of the first kernel whose name contains `needle` in a rocprofv3 kernel_stats.csv."""
+    try:
+        for row in csv.DictReader(open(P(csv_name))):
+            if needle in row["Name"]:
+                return float(row["AverageNs"]) / 1e3, int(row["Calls"])
+    except OSError:
+        pass
+    return None, 0
+
+
+def pmc(txt_name, kernel, counter):
+    try:
+        name = None
+        for line in open(P(txt_name)):
+            if not line.startswith(" "):
+                name = line
+            m = re.match(r"\s+%s\s+n=(\d+)\s+mean\s+([0-9.e+]+)" % counter, line)
+            if m and name and kernel in name:
+                return float(m.group(2))
+    except OSError:
+        pass
+    return None
+
+
+def jload(name):
+    try:
+        txt = open(P(name)).read().strip().splitlines()[-1]
+        return json.loads(txt) if txt.startswith("{") else json.load(open(P(name)))
+    except (OSError, ValueError, IndexError):
+        try:
+            return json.load(open(P(name)))
+        except (OSError, ValueError):
+            return None
+
+
+def f(x, fmt="%.1f", na="n/a"):
+    return na if x is None else fmt % x
+
+
+rows = []
+bench = jload("bench_line.json")
+ALG_FLOPS, ALG_BYTES = 31.15008e9, 73.2e6
+# ---- the dominant kernel ------------------------------------------------------------------------------------------
+us, calls = kavg("bench_fast_kernel_stats.csv", "tap2_bank_kernel")
+ev = bench["roofline"]["kernel_ms_per_launch"] * 1e3 if bench else None
+tr = jload("traffic_fast.json")
+busy, sqb = pmc("pmc_sq1.txt", "tap2_bank_kernel", "SQ_VALU_MFMA_BUSY_CYCLES"), pmc("pmc_sq1.txt", "tap2_bank_kernel", "SQ_BUSY_CYCLES")
+wavecyc = pmc("pmc_sq1.txt", "tap2_bank_kernel", "SQ_WAVE_CYCLES")
+rows.append(("`tap2_bank_kernel<23,0>` (`TSR_FAST`, narrow rows)", "config 2, every launch streams its frames from HBM",
+             "31.15 Gflop, 73.2 MB (366 B/frame)",
+             "%s us hipEvents in `bench.py` (`%s_bench_line.json`); %s us rocprofv3 average of %d launches of a profiled run (`%s_bench_fast_kernel_stats.csv`)"
+             % (f(ev, "%.2f"), R, f(us, "%.2f"), calls, R),
+             "%s Tflop/s = %s of the 5 PF int8 peak; %s TB/s = %s of HBM; PMC traffic %s MB = %sx algorithmic (`%s_traffic_fast.json`); matrix pipe busy %s of the waves' lifetime (`%s_pmc_sq1.txt`)"
+             % (f(ALG_FLOPS / ev / 1e6 if ev else None, "%.0f"), f(ALG_FLOPS / ev / 1e6 / 5000 if ev else None, "%.3f"),
+                f(ALG_BYTES / ev / 1e6 if ev else None, "%.2f"), f(ALG_BYTES / ev / 1e6 / 8 if ev else None, "%.3f"),
+                f(tr["hbm_bytes_per_launch"] / 1e6 if tr else None), f(tr["ratio_to_algorithmic"] if tr else None, "%.2f"), R,
+                f(100.0 * busy / (4 * wavecyc) * 4 if busy and wavecyc else None, "%.0f %%"), R),
+             "instruction issue beside the matrix pipe + the per-workgroup prologue (section 4.1)"))
+if bench and "modes" in bench:
+    for mode, kern, note in (("fast24", "alt_bank_kernel<12,3>", "three limbs"), ("exact", "exact_mfma_kernel", "scalar issue (operand funnel)")):
+        m = bench["modes"].get(mode)
+        if m:
+            us2, c2 = kavg("bench_%s_kernel_stats.csv" % mode, kern.split("<")[0])
+            rows.append(("`%s` (`%s`)" % (kern, "TSR_FAST|TSR_W24" if mode == "fast24" else "TSR_EXACT"), "config 2", "same",
+                         "%s us hipEvents (`%s_bench_line.json`, `modes.%s`); %s us rocprofv3 average (`%s_bench_%s_kernel_stats.csv`)"
+                         % (f(m["kernel_ms_per_launch"] * 1e3, "%.1f"), R, mode, f(us2, "%.1f"), R, mode),
+                         "%s Tflop/s algorithmic; %s M frames/s" % (f(m["alg_tflops"], "%.0f"), f(m["frames_per_s"] / 1e6, "%.0f")), note))
+    x10 = bench.get("configs", {}).get("config2_x10_one_launch")
+    if x10:
+        rows.append(("`tap2_bank_kernel<23,0>`, 10 000 utterances in one launch", "config 2 ten times over (prologue amortised 10x)", "311.5 Gflop, 732 MB",
+                     "%s us per launch = %s us per 1000 utterances (`%s_bench_line.json`, `configs.config2_x10_one_launch`)"
+                     % (f(x10["kernel_ms_per_launch"] * 1e3, "%.1f"), f(x10["kernel_us_per_1000_utterances"], "%.2f"), R),
+                     "%s of the int8 peak; %s TB/s of algorithmic bytes" % (f(x10["frac_of_int8_peak"], "%.3f"), f(x10["hbm_gbs_alg"] / 1e3, "%.2f")),
+                     "the steady-state loop (matrix pipe 81 % busy inside it)"))
+# ---- config 3 -----------------------------------------------------------------------------------------------------
+c3 = {k: kavg("config3_kernel_stats.csv", k) for k in ("code_parts_mfma_kernel", "code_parts_recheck_kernel", "spread_mask_multi_kernel",
+                                                        "fast_bank_kernel<11, 2, false, 2, 1, true>", "frag_epilogue_kernel")}
+t3 = jload("config3_traffic.json")
+if c3["code_parts_mfma_kernel"][0]:
+    bank = 6 * c3["fast_bank_kernel<11, 2, false, 2, 1, true>"][0] + c3["frag_epilogue_kernel"][0]
+    tot = c3["code_parts_mfma_kernel"][0] + c3["code_parts_recheck_kernel"][0] + c3["spread_mask_multi_kernel"][0] + bank
+    rows.append(("config-3 chain: `code_parts_mfma_kernel<8>` + recheck + `spread_mask_multi_kernel` (bit form) + 6 K-phases of `fast_bank_kernel<11,2,bits>` + epilogue",
+                 "config 3: 8.2 M locations x 50 parts; D = 2050 bank", "164 + 177 Gflop, 73.2 MB algorithmic",
+                 "%s + %s + %s + %s = %s us of kernels (`%s_config3_kernel_stats.csv`)"
+                 % (f(c3["code_parts_mfma_kernel"][0]), f(c3["code_parts_recheck_kernel"][0]), f(c3["spread_mask_multi_kernel"][0]), f(bank), f(tot), R),
+                 "%s Tflop/s over the chain; PMC traffic %s MB = %sx algorithmic (`%s_config3_traffic.json`; round 2: ~950 MB by its own sizes)"
+                 % (f(341e9 / tot / 1e6, "%.0f"), f(t3["hbm_bytes_per_chain"] / 1e6 if t3 else None, "%.0f"), f(t3["ratio_to_algorithmic"] if t3 else None, "%.1f"), R),
+                 "VALU beside the matrix cores (coder: arg-max keys; bank: 22 MFMAs per skew emission)"))
+# ---- config 4 share -----------------------------------------------------------------------------------------------
+us4, c4 = kavg("c45_kernel_stats.csv", "tap2_bank_kernel")
+if us4:
+    rows.append(("`tap2_bank_kernel<23,3>` (10 column groups, XCD-aware) + key decode", "config 4 share: 1250 utterances, M = 64", "338 Gflop (valid windows)",
+                 "%s us rocprofv3 average (`%s_c45_kernel_stats.csv`); per-pass hipEvent times of all five variants: `%s_config45_timing.txt`" % (f(us4), R, R),
+                 "%s Tflop/s = %s of the int8 peak" % (f(338e9 / us4 / 1e6, "%.0f"), f(338e9 / us4 / 1e6 / 5000, "%.3f")), "as config 2"))
+# ---- next rows ----------------------------------------------------------------------------------------------------
+for csvn, needle, label, work, alg, bound in (
+        ("classify_kernel_stats.csv", "isolated_windows_kernel", "`isolated_windows_kernel`", "133 k positions x 8 templates (N1)", "24.5 Gflop in `detect_float`'s order", "vector instructions (f32 chains in the reference's order)"),
+        ("edges_kernel_stats.csv", "edge_block_bin_kernel", "`edge_block_bin_kernel<40>`", "1000 spectrograms -> edge corpus (N3)", "72 MB in, 74 MB out", "instruction issue (stencil + select per block); round 2: 445 us"),
+        ("edges_kernel_stats.csv", "edge_block_wave_kernel", "`edge_block_wave_kernel<32>`", "1000 spectrograms -> edge corpus (N3)", "72 MB in, 74 MB out", "the per-block radix select")):
+    u, c = kavg(csvn, needle)
+    if u:
+        extra = ("%s Tflop/s" % f(24.5e9 / u / 1e6, "%.1f")) if "isolated" in needle else ("%s TB/s" % f(146e6 / u / 1e6, "%.2f"))
+        rows.append((label, work, alg, "%s us rocprofv3 average of %d (`%s_%s`)" % (f(u), c, R, csvn), extra, bound))
+out = ["| kernel | workload | algorithmic work per launch | time (source) | achieved | bound by |", "|---|---|---|---|---|---|"]
+out += ["| " + " | ".join(r) + " |" for r in rows]
+table = "\n".join(out)
+if "--write" in sys.argv:
+    path = os.path.join(ROOT, "DESIGN.md")
+    s = open(path).read()
+    a, b = s.index("<!-- table:begin -->"), s.index("<!-- table:end -->")
+    open(path, "w").write(s[:a] + "<!-- table:begin -->\n" + table + "\n" + s[b:])
+    print("DESIGN.md table rewritten from profiles/%s_*" % R)
+else:
+    print(table)

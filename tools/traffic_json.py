@@ -1,4 +1,4 @@
-"""HBM bytes per launch of the dominant bank kernel from the two PMC passes of tools/profile_r02.sh traffic
+"""HBM bytes per launch of the dominant bank kernel from the two PMC passes of tools/profile_r03.sh traffic
 (pmc_summary.py texts of FETCH_SIZE and WRITE_SIZE) -> profiles/r02_traffic_<mode>.json, the file bench.py quotes in
 roofline.traffic.  gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream, read side x2
 (MI355X_MICROARCH.md, HBM section); both counters are in KiB."""
@@ -29,7 +29,7 @@ j = {"mode": mode, "kernel": kf.split("(")[0].replace("void ", ""),
      "working_set": "16 device-resident copies of the config-2 corpus (1.2 GB, 4.7x the 256 MiB Infinity Cache), each launch "
                     "streams its 73.6 MB of frames from HBM",
      "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 3 --warmup 1 --replicas 16 "
-                "--no-cpu-baseline --no-modes --mode %s (two separate passes; tools/profile_r02.sh traffic)" % mode,
+                "--no-cpu-baseline --no-modes --mode %s (two separate passes; tools/profile_r03.sh traffic)" % mode,
      "counters": {"FETCH_SIZE": {"launches": nf, "mean_KiB": fetch}, "WRITE_SIZE": {"launches": nw, "mean_KiB": write}},
      "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream -> read side x2 "
                    "(MI355X_MICROARCH.md, HBM)",
