@@ -61,11 +61,12 @@ rows.append(("`tap2_bank_kernel<23,0>` (`TSR_FAST`, narrow rows)", "config 2, ev
              "31.15 Gflop, 73.2 MB (366 B/frame)",
              "%s us hipEvents in `bench.py` (`%s_bench_line.json`); %s us rocprofv3 average of %d launches of a profiled run (`%s_bench_fast_kernel_stats.csv`)"
              % (f(ev, "%.2f"), R, f(us, "%.2f"), calls, R),
-             "%s Tflop/s = %s of the 5 PF int8 peak; %s TB/s = %s of HBM; PMC traffic %s MB = %sx algorithmic (`%s_traffic_fast.json`); matrix pipe busy %s of the waves' lifetime (`%s_pmc_sq1.txt`)"
+             "%s Tflop/s = %s of the 5 PF int8 peak; %s TB/s = %s of HBM; PMC traffic %s MB = %sx algorithmic (`%s_traffic_fast.json`); matrix pipe busy %s of the launch (`SQ_VALU_MFMA_BUSY_CYCLES` / 1024 SIMDs / launch cycles, `%s_pmc_sq1.txt`)"
              % (f(ALG_FLOPS / ev / 1e6 if ev else None, "%.0f"), f(ALG_FLOPS / ev / 1e6 / 5000 if ev else None, "%.3f"),
                 f(ALG_BYTES / ev / 1e6 if ev else None, "%.2f"), f(ALG_BYTES / ev / 1e6 / 8 if ev else None, "%.3f"),
                 f(tr["hbm_bytes_per_launch"] / 1e6 if tr else None), f(tr["ratio_to_algorithmic"] if tr else None, "%.2f"), R,
-                f(100.0 * busy / (4 * wavecyc) * 4 if busy and wavecyc else None, "%.0f %%"), R),
+                # SQ_BUSY_CYCLES sums 32 shader engines (8 XCDs x 4): / 32 = cycles of the launch; 1024 SIMDs on the chip
+                f(100.0 * busy / (1024.0 * sqb / 32.0) if busy and sqb else None, "%.0f %%"), R),
              "instruction issue beside the matrix pipe + the per-workgroup prologue (section 4.1)"))
 if bench and "modes" in bench:
     for mode, kern, note in (("fast24", "alt_bank_kernel<12,3>", "three limbs"), ("exact", "exact_mfma_kernel", "scalar issue (operand funnel)")):
