@@ -251,10 +251,17 @@ def config3(ctx, corpus, flags, layout=None):
     info = parts.info()
     edges.close()
     fe, bk = min(fe_ms[1:]), min(bank_ms[1:])
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "r03_config3_traffic.json")
+    if layout is None and os.path.exists(tp):
+        tj = json.load(open(tp))
+        traffic = {"hbm_bytes_per_chain": tj["hbm_bytes_per_chain"], "ratio_to_algorithmic": tj["ratio_to_algorithmic"],
+                   "source": "profiles/r03_config3_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
+                   "measured_in_this_run": False}
     return {"front_end_stream_ms": fe, "front_end_wall_ms": min(fe_wall[1:]), "bank_D2050_kernel_ms": bk,
             "frames_per_s": frames / ((fe + bk) * 1e-3), "frames": frames,
             "part_corpus": {"layout": "+".join(k for k in ("bits", "bytes") if lay[k]), "resident_MB": lay["feature_bytes"] / 1e6},
-            "patch_locations": info["locations"], "f64_rechecked": info["rechecked"],
+            "patch_locations": info["locations"], "f64_rechecked": info["rechecked"], "traffic": traffic,
             "what": "code_parts(K=50,thr=12) -> argmax -> spread(2,2) -> 8x32-tap bank on D=2050, one GPU; front_end_stream_ms = "
                     "hipEvents around tsr_corpus_part_features (coder, f64 re-evaluation, dilation and the allocation of the "
                     "output corpus), bank = one TSR_FAST pass over the resident part corpus"}
@@ -418,6 +425,10 @@ def main():
         return dry_run_ranks(world, rank)
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this driver)
+    if world > 1:
+        # one node by contract: RCCL's bootstrap rendezvous over the loopback interface (a container's hostname or
+        # outward interface need not resolve); the data of the one collective goes over xGMI / shared memory either way
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     allcores = cpu_allcores() if (args.extras and world == 1) else None   # forks: before any GPU call
     # (TSR_DEVICE pins every rank to one GPU: a rehearsal of the N > 1 control flow on a one-GPU box)
     ctx = tsr_hip.Context(int(os.environ.get("TSR_DEVICE", local_rank)))

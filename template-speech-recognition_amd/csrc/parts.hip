@@ -467,6 +467,109 @@ int tsr_launch_out_geometry(tsr_ctx *ctx, const int64_t *d_ooff, const int32_t *
 
 // `d_out` rows need no zeroing when this returns with *wrote_all = true (mask kernel); the
 // byte-scatter kernel (K > 64) needs them zeroed and does that itself.
+// The dilation straight into the bit form, in registers (round 3): one LANE per frequency bin (N1, O1 <= 64), one wave
+// walks kLaneFrames consecutive output frames.  Per frame: the lane ORs the one-hot masks of its bin over the <= 2 r0 + 1
+// source rows (byte ids: a coalesced N1-byte read per row, L1/L2 hits after the first frame), the output column takes the
+// masks of the source bins of its box by lane shuffles, the graph closure runs on the 64-bit mask, and the frame's bit
+// stream (bit oj K + k) is assembled per output DWORD from the one or two (K >= 32) lanes that overlap it -- no LDS, no
+// atomics -- and stored into the phase planes.  Same bits as spread_mask_multi_kernel (test_part_corpus_bit_rows,
+// test_config3_*, tools/fuzz_parts.py).
+constexpr int kLaneFrames = 8;
+
+__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int src)
+{
+    return ((unsigned long long)(unsigned)__shfl((int)(v >> 32), src) << 32) | (unsigned)__shfl((int)v, src);
+}
+
+// wavefront shifts by one lane (DPP, zero fill at the ends): with a symmetric box the direction does not matter
+__device__ __forceinline__ unsigned long long wave_shift1(unsigned long long v, bool up)
+{
+    const int lo = (int)v, hi = (int)(v >> 32);
+    const int l2 = up ? __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xF, 0xF, true) : __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xF, 0xF, true);
+    const int h2 = up ? __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xF, 0xF, true) : __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xF, 0xF, true);
+    return ((unsigned long long)(unsigned)h2 << 32) | (unsigned)l2;
+}
+
+template <bool IDS8>
+__global__ __launch_bounds__(256) void spread_lane_bits_kernel(
+    const void *__restrict__ Aany, int N1, int r0, int r1, int K, int g1, int O1, int64_t P_out,
+    const int32_t *__restrict__ out_src_row, const int32_t *__restrict__ out_src_lo, const int32_t *__restrict__ out_src_hi,
+    const uint64_t *__restrict__ graph_masks /*[K] or null*/, uint32_t *__restrict__ o32, int bit_pw, int bit_nph, int64_t bit_rows)
+{
+    __shared__ unsigned long long strip[4][kLaneFrames][64];  // per wave: the frames' column masks
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * kLaneFrames;
+    if (q0 >= P_out) return;
+    const int nf = (int)min((int64_t)kLaneFrames, P_out - q0);
+    const int nw = bit_nph * bit_pw;                      // dwords of a frame's bit form
+    const int j = lane * g1;                              // source bin of this lane's output column
+    const int lo1 = max(j - r1, 0), hi1 = min(j + r1 + 1, N1);
+    // ---- A. per frame: rows OR-ed per bin, box over the bins, closure -> strip[f][column] ------------------------
+    for (int f = 0; f < nf; ++f) {
+        const int64_t q = q0 + f;
+        const int i = out_src_row[q];
+        const int lo = max(i - r0, out_src_lo[q]), hi = max(min(i + r0 + 1, out_src_hi[q]), lo);  // (wave-uniform)
+        unsigned long long m = 0;
+        if (lane < N1)
+            for (int x0 = lo; x0 < hi; ++x0) {
+                const int64_t at = (int64_t)x0 * N1 + lane;
+                const int p = IDS8 ? (int)static_cast<const uint8_t *>(Aany)[at] : static_cast<const int32_t *>(Aany)[at];
+                m |= p > 0 ? 1ull << (p - 1) : 0ull;
+            }
+        unsigned long long mc = m;                        // this output column's box over the source bins
+        if (g1 == 1) {                                    // neighbours by wavefront shifts (bins >= N1 hold no parts)
+            unsigned long long up = m, dn = m;
+            for (int d = 0; d < r1; ++d) {
+                up = wave_shift1(up, true);
+                dn = wave_shift1(dn, false);
+                mc |= up | dn;
+            }
+        } else {
+            mc = 0;
+            for (int x1 = lo1; x1 < lo1 + 2 * r1 + 1; ++x1) {  // (every lane runs the same number of shuffles)
+                const unsigned long long v = shfl64(m, x1 & 63);
+                if (x1 < hi1) mc |= v;
+            }
+        }
+        if (lane >= O1) mc = 0;
+        if (graph_masks)
+            for (int a = 0; a < K; ++a)
+                if ((mc >> a) & 1) mc |= graph_masks[a];
+        strip[wave][f][lane] = mc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- B. the bit streams (bit oj K + k), one output DWORD per lane and round, the same dword of every frame:
+    //      bits [32 w, 32 w + 32) come from the columns first .. first + cmax - 1 at fixed shifts -----------------------
+    const int cmax = (31 + K) / K + 1;                    // output columns that can overlap one dword
+    for (int w0 = 0; w0 < nw; w0 += 64) {
+        const int w = w0 + lane;
+        if (w >= nw) continue;
+        const int first = (32 * w) / K;
+        const int ph = w / bit_pw, jj = w - ph * bit_pw;
+        uint32_t *dst = o32 + ((int64_t)ph * bit_rows + q0) * bit_pw + jj;
+        for (int f = 0; f < nf; ++f) {
+            unsigned acc = 0;
+            for (int c = 0; c < cmax; ++c) {
+                const int oj = first + c;
+                const int pos = oj * K - 32 * w;           // bit of the dword where this column's mask starts
+                if (oj < O1 && pos < 32) {
+                    const unsigned long long v = strip[wave][f][oj];
+                    acc |= pos >= 0 ? (unsigned)(v << pos) : (unsigned)(v >> -pos);
+                }
+            }
+            dst[(int64_t)f * bit_pw] = acc;
+        }
+    }
+}
+
+// (development switch: TSR_SPREADK=old at library load keeps the LDS-stream kernel for the bit form, for A/B timing)
+static const bool g_spread_old = [] {
+    const char *e = getenv("TSR_SPREADK");
+    return e && e[0] == 'o';
+}();
+
 static int spread_multi_words(int Dp_out, int bit_words) { return std::max((Dp_out >> 5) + 3, bit_words); }
 static size_t spread_multi_lds(int64_t N1, int Dp_out, int bit_words)
 {
@@ -493,6 +596,20 @@ int tsr_launch_spread_stream(tsr_ctx *ctx, const int32_t *d_A, int64_t N1, int r
     if (d_out_bits && !tsr_spread_packs_bits(N1, r0, K, Dp_out, Bp)) {
         tsr_set_error("spread: bit rows asked for a geometry the mask kernel does not cover");
         return TSR_ERR_UNSUPPORTED;
+    }
+    if (d_out_bits && N1 <= 64 && O1 <= 64 && K <= 64 && !g_spread_old) {  // the register kernel writes the bit form directly
+        const int64_t fpb = 4 * kLaneFrames;
+        const dim3 grid((unsigned)((P_out + fpb - 1) / fpb));
+        if (ids8)
+            hipLaunchKernelGGL(spread_lane_bits_kernel<true>, grid, dim3(256), 0, ctx->stream, (const void *)d_A, (int)N1, r0, r1, (int)K, g1,
+                               (int)O1, P_out, d_src_row, d_src_lo, d_src_hi, d_graph ? d_graph_masks : nullptr,
+                               reinterpret_cast<uint32_t *>(d_out_bits), bit_pw, bit_nph, bit_rows);
+        else
+            hipLaunchKernelGGL(spread_lane_bits_kernel<false>, grid, dim3(256), 0, ctx->stream, (const void *)d_A, (int)N1, r0, r1, (int)K, g1,
+                               (int)O1, P_out, d_src_row, d_src_lo, d_src_hi, d_graph ? d_graph_masks : nullptr,
+                               reinterpret_cast<uint32_t *>(d_out_bits), bit_pw, bit_nph, bit_rows);
+        TSR_HIP(hipGetLastError());
+        return TSR_OK;
     }
     const size_t per_wave = ((size_t)(2 * r0 + 1) * N1 * 8 + ((size_t)(Dp_out >> 5) + 3) * 4 + 7) / 8 * 8;
     const size_t lds = (size_t)kSpreadWaves * per_wave;

@@ -46,11 +46,36 @@ for case in range(n_cases):
     corpus = tsr_hip.Corpus(np.concatenate(edges).reshape(int(offs[-1]), -1), offs)
     parts = tsr_hip.Parts(lp, lip)
     res = {}
+    res_bank = ""
     for mode in (tsr_hip.TSR_PARTS_MFMA, tsr_hip.TSR_PARTS_VALU):
         if mode == tsr_hip.TSR_PARTS_MFMA and not parts.info()["mfma_available"]:
             continue
         parts.set_mode(mode)
         pc = corpus.part_features(parts, thr, spread=spread, graph=graph, grid=grid, fast=fast)
+        if case % 3 == 0 and pc.P > 0:   # a random bank on the part corpus: the bit form (read as bits where the kernel can) vs byte rows
+            rb = np.random.default_rng(case)
+            O1 = pc.D // K
+            filt = synth.bank(rb, synth.background(rb, (O1, K)), [int(x) for x in rb.integers(1, 40, size=int(rb.choice([1, 3, 8, 9])))])
+            bank = tsr_hip.Bank(filt)
+            pc.score(bank, tsr_hip.TSR_FAST)
+            sb = pc.download() + (pc.score_all(bank, tsr_hip.TSR_FAST),)
+            with tsr_hip.default_ctx().option(tsr_hip.TSR_OPT_PART_LAYOUT, tsr_hip.TSR_PART_LAYOUT_BYTES):
+                pcb = corpus.part_features(parts, thr, spread=spread, graph=graph, grid=grid, fast=fast)
+            pcb.score(bank, tsr_hip.TSR_FAST)
+            sy = pcb.download() + (pcb.score_all(bank, tsr_hip.TSR_FAST),)
+            pc.score(bank, tsr_hip.TSR_EXACT)
+            se = pc.download()
+            if not all(np.array_equal(x, y) for x, y in zip(sb, sy)):
+                bank_bad = " bank scores differ between the bit form and byte rows"
+            elif len(se[0]) and float(np.max(np.abs(sb[0] - se[0]) / np.maximum(np.abs(se[0]), 1.0))) > 1e-4:
+                # (dense part features: the norm of include/tsr.h -- 1e-4 of the sum of magnitudes of the set taps)
+                mags = tsr_hip.Bank([(np.abs(W), 0.0) for W, _ in filt]).score_all(pc.download_feats(), pc.offsets)
+                ok2 = np.all(np.abs(sb[2].astype(np.float64) - pc.score_all(bank, tsr_hip.TSR_EXACT)) <= 1e-4 * np.maximum(mags, 1.0))
+                bank_bad = "" if ok2 else " fast bank scores on the bit form off the exact ones"
+            else:
+                bank_bad = ""
+            res_bank += bank_bad
+            pcb.close(); bank.close()
         res[mode] = pc.download_feats()
         if mode == tsr_hip.TSR_PARTS_MFMA:
             i = parts.info()
@@ -66,7 +91,7 @@ for case in range(n_cases):
         w = np.ascontiguousarray(sp[::grid[0], ::grid[1]])
         want.append(w.reshape(w.shape[0], w.shape[1] * K))
     want = np.concatenate(want) if want else np.zeros((0, 0), np.uint8)
-    msg = ""
+    msg = res_bank
     for mode, got in res.items():
         if got.shape[0] != want.shape[0] or (want.size and not np.array_equal(got, want)):
             msg += " mode %d differs from the oracle" % mode
