@@ -71,6 +71,16 @@ struct PmArgs {
     uint32_t *list;            // [n][2]: location, full (slot 0 of code_parts_fast in play)
 };
 
+// (a << sh) + b in one instruction (hipcc splits the key of a part slot, (hi << 14) + (lo << 6) + base, into two shifts
+// and a three-operand add: three instructions where two do)
+template <int SH>
+__device__ __forceinline__ int lshl_add(int a, int b)
+{
+    int d;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(SH), "v"(b));
+    return d;
+}
+
 __device__ __forceinline__ int med3(int a, int b, int c)
 {
     int d;
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
                     const i32x4 kc = *reinterpret_cast<const i32x4 *>(kcl + (half * 2 + mt) * 16 + r4 * 4);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const int key = (acc[1][r4 * 4 + c] << 14) + (acc[0][r4 * 4 + c] << 6) + kc[c];
+                        const int key = lshl_add<14>(acc[1][r4 * 4 + c], lshl_add<6>(acc[0][r4 * 4 + c], kc[c]));
                         second = med3(best, second, key);
                         best = max(best, key);
                         if (a.fast) vsum += (float)(key >> 6);

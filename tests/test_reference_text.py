@@ -247,6 +247,11 @@ def test_dropin_host_logic_is_the_references_code():
     r_et = py2ref.load("estimate_template", ["construct_linear_filters", "construct_linear_filter"])
     r_cl = py2ref.load("classification", ["map_coarse_frame_to_range", "get_coarse_segment", "_stretch_template"])
     r_rf = py2ref.load("roc_functions", ["get_cluster_starts_ends"])
+    import template_speech_rec.edge_signal_proc as esp
+    r_esp = py2ref.load("edge_signal_proc", ["compute_edge_feature_row_breaks"])
+    for base in (1, 7, 45):
+        assert np.array_equal(esp.compute_edge_feature_row_breaks(base, esp.EDGE_ORIENTATIONS),
+                              r_esp["compute_edge_feature_row_breaks"](base, esp.EDGE_ORIENTATIONS))
     rng = np.random.default_rng(1808)
     for case in range(25):
         H, T, K = int(rng.integers(2, 20)), int(rng.integers(3, 60)), int(rng.integers(1, 6))

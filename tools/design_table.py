@@ -85,16 +85,16 @@ if bench and "modes" in bench:
                      "%s of the int8 peak; %s TB/s of algorithmic bytes" % (f(x10["frac_of_int8_peak"], "%.3f"), f(x10["hbm_gbs_alg"] / 1e3, "%.2f")),
                      "the steady-state loop (matrix pipe 81 % busy inside it)"))
 # ---- config 3 -----------------------------------------------------------------------------------------------------
-c3 = {k: kavg("config3_kernel_stats.csv", k) for k in ("code_parts_mfma_kernel", "code_parts_recheck_kernel", "spread_mask_multi_kernel",
+c3 = {k: kavg("config3_kernel_stats.csv", k) for k in ("code_parts_mfma_kernel", "code_parts_recheck_kernel", "spread_",
                                                         "fast_bank_kernel<11, 2, false, 2, 1, true>", "frag_epilogue_kernel")}
 t3 = jload("config3_traffic.json")
 if c3["code_parts_mfma_kernel"][0]:
     bank = 6 * c3["fast_bank_kernel<11, 2, false, 2, 1, true>"][0] + c3["frag_epilogue_kernel"][0]
-    tot = c3["code_parts_mfma_kernel"][0] + c3["code_parts_recheck_kernel"][0] + c3["spread_mask_multi_kernel"][0] + bank
-    rows.append(("config-3 chain: `code_parts_mfma_kernel<8>` + recheck + `spread_mask_multi_kernel` (bit form) + 6 K-phases of `fast_bank_kernel<11,2,bits>` + epilogue",
+    tot = c3["code_parts_mfma_kernel"][0] + c3["code_parts_recheck_kernel"][0] + c3["spread_"][0] + bank
+    rows.append(("config-3 chain: `code_parts_mfma_kernel<8>` + recheck + `spread_lane_bits_kernel` (dilation into the bit form) + 6 K-phases of `fast_bank_kernel<11,2,bits>` + epilogue",
                  "config 3: 8.2 M locations x 50 parts; D = 2050 bank", "164 + 177 Gflop, 73.2 MB algorithmic",
                  "%s + %s + %s + %s = %s us of kernels (`%s_config3_kernel_stats.csv`)"
-                 % (f(c3["code_parts_mfma_kernel"][0]), f(c3["code_parts_recheck_kernel"][0]), f(c3["spread_mask_multi_kernel"][0]), f(bank), f(tot), R),
+                 % (f(c3["code_parts_mfma_kernel"][0]), f(c3["code_parts_recheck_kernel"][0]), f(c3["spread_"][0]), f(bank), f(tot), R),
                  "%s Tflop/s over the chain; PMC traffic %s MB = %sx algorithmic (`%s_config3_traffic.json`; round 2: ~950 MB by its own sizes)"
                  % (f(341e9 / tot / 1e6, "%.0f"), f(t3["hbm_bytes_per_chain"] / 1e6 if t3 else None, "%.0f"), f(t3["ratio_to_algorithmic"] if t3 else None, "%.1f"), R),
                  "VALU beside the matrix cores (coder: arg-max keys; bank: 22 MFMAs per skew emission)"))

@@ -16,9 +16,10 @@ for line in open(txt):
     m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE)\s+n=(\d+)\s+mean\s+([0-9.e+]+)\s+sum\s+([0-9.e+]+)", line)
     if m and name and sec == m.group(1):
         data.setdefault(name, {})[sec] = {"calls": int(m.group(2)), "mean_KiB": float(m.group(3)), "sum_KiB": float(m.group(4))}
-chain = ["code_parts_mfma_kernel<8>", "code_parts_recheck_kernel", "spread_mask_multi_kernel", "tsr_fast::fast_bank_kernel<11, 2, false, 2, 1, true>",
-         "frag_epilogue_kernel", "out_geometry_kernel"]
-front = data["code_parts_mfma_kernel<8>"]["FETCH_SIZE"]["calls"]   # front-end calls in the run
+# the kernels of the chain, by the stem of their names (the dilation kernel of the bit form changed during round 3)
+stems = ["code_parts_mfma_kernel", "code_parts_recheck_kernel", "spread_", "fast_bank_kernel", "frag_epilogue_kernel", "out_geometry_kernel"]
+chain = [k for st in stems for k in data if st in k]
+front = next(v for k, v in data.items() if "code_parts_mfma_kernel" in k)["FETCH_SIZE"]["calls"]   # front-end calls in the run
 per = {}
 total = 0.0
 for k in chain:
