@@ -377,30 +377,28 @@ constexpr int kEdgeCap = 512;  // positive values of a block an orientation pack
 // shifts of that mask, and the frames are written straight from the eight orientations' masks as 8-byte groups
 // [frame][h * 8 + e] -- no byte tile, no binary block in LDS.
 template <int WMAX>
-__global__ __launch_bounds__(512, WMAX <= 48 ? 4 : 2) void edge_block_bin_kernel(const EdgeArgs a)
+__global__ __launch_bounds__(256, WMAX <= 48 ? 4 : 2) void edge_block_bin_kernel(const EdgeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t esm[];
-    const int tid = threadIdx.x, lane = tid & 63, e = tid >> 6;  // wave = orientation
+    const int tid = threadIdx.x, lane = tid & 63, pair = tid >> 6;  // wave = orientation PAIR (both signs of one difference)
     const int H = a.H;
     const int32_t *it = a.item + (size_t)blockIdx.x * 4;
     const int u = it[0], c0 = it[1], W = it[2], keep0 = it[3];
     const int64_t o = a.utt_off[u];
     const int T = (int)(a.utt_off[u + 1] - o);
     unsigned long long *masks = reinterpret_cast<unsigned long long *>(esm);   // [8][64]
-    int *hist = reinterpret_cast<int *>(masks + 8 * 64) + e * 256;              // this wave's [256]
-    unsigned long long *comp = reinterpret_cast<unsigned long long *>(reinterpret_cast<int *>(masks + 8 * 64) + 8 * 256) + e * kEdgeCap;
-    double *Sl = reinterpret_cast<double *>(reinterpret_cast<unsigned long long *>(reinterpret_cast<int *>(masks + 8 * 64) + 8 * 256) + 8 * kEdgeCap);
+    int *hist = reinterpret_cast<int *>(masks + 8 * 64) + pair * 256;           // this wave's [256]
+    unsigned long long *comp = reinterpret_cast<unsigned long long *>(reinterpret_cast<int *>(masks + 8 * 64) + 4 * 256) + pair * kEdgeCap;
+    double *Sl = reinterpret_cast<double *>(reinterpret_cast<unsigned long long *>(reinterpret_cast<int *>(masks + 8 * 64) + 4 * 256) + 4 * kEdgeCap);
     // the block's spectrogram frames (one before, two behind: the stencil's reach), staged once with coalesced loads
     const int f_lo = max(c0 - 1, 0), f_hi = min(c0 + W + 2, T);
     {
         const double *src = a.S + (o + f_lo) * H;
-        for (int i = tid; i < (f_hi - f_lo) * H; i += 512) Sl[i] = src[i];
+        for (int i = tid; i < (f_hi - f_lo) * H; i += 256) Sl[i] = src[i];
     }
     __syncthreads();
     const int h = lane;
     const bool hon = h < H, hin = h >= 1 && h < H - 2;
-    const int pair = e >> 1;
-    const double sg = (e & 1) ? -1.0 : 1.0;
     // ---- 1. stencil: this lane's bin through the frames of the block.  For every orientation pair the three differences
     //      are d = S[p1] - S[p0], lo = S[p0] - S[pl], hi = S[ph] - S[p1] at fixed element offsets from S[h][t] (wave-
     //      uniform, set once), so the loop over the frames is one straight line for all orientations:
@@ -424,8 +422,11 @@ __global__ __launch_bounds__(512, WMAX <= 48 ? 4 : 2) void edge_block_bin_kernel
         if (c >= c_lo && c < c_hi) {  // (wave-uniform)
             const double *q = sp + c * H;
             const double s0 = q[o0], s1 = q[o1];
-            const double d = (s1 - s0) * sg, lo = (s0 - q[ol]) * sg, hi = (q[oh] - s1) * sg;
-            bool keep = lane_ok && d >= lo && d >= hi && d >= 0.0;
+            const double d = s1 - s0, lo = s0 - q[ol], hi = q[oh] - s1;
+            // orientation 2 pair keeps d where it is >= both neighbours and >= 0; orientation 2 pair + 1 does the same on
+            // the negated differences, i.e. keeps -d where d <= both and <= 0: one signed value serves both (they
+            // exclude each other unless d == 0, which neither counts as an edge)
+            bool keep = lane_ok && ((d >= lo && d >= hi && d >= 0.0) || (d <= lo && d <= hi && d <= 0.0));
             if (mk) keep = keep && mk[c * H] != 0;
             x = keep ? d : 0.0;
         }
@@ -435,151 +436,159 @@ __global__ __launch_bounds__(512, WMAX <= 48 ? 4 : 2) void edge_block_bin_kernel
     //      into a per-wave LDS strip (ballot + mbcnt: no atomics) and read back kEdgeCap / 64 to a lane; the radix select
     //      (8-bit digits on the f64 bit patterns -- positive doubles order like their bits -- most significant first,
     //      stops when one candidate is left) then walks n / 64 keys per lane and pass instead of all W frames of its bin.
-    int n = 0;
+    const int d0 = pair == 0 ? 0 : (pair == 3 ? -1 : 1), d1 = pair == 1 ? 0 : 1;
+    const unsigned long long wmask = W >= 64 ? ~0ull : ((1ull << W) - 1ull);
+    for (int sgn = 0; sgn < 2; ++sgn) {  // the two orientations of the pair: the positive values, then the negated negative ones
+        const int e = 2 * pair + sgn;
+        if (sgn) {  // the second orientation works on the negated values (in place: the first is done with them)
 #pragma unroll
-    for (int c = 0; c < WMAX; ++c) {
-        const bool p = v[c] > 0.0;
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(p);
-        const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-        if (p && pos < kEdgeCap) comp[pos] = (unsigned long long)__double_as_longlong(v[c]);
-        n += __builtin_popcountll(bal);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double thr = 0.0;
-    if (n > 0) {
-        constexpr int KPL = kEdgeCap / 64;
-        const bool packed = n <= kEdgeCap;  // (wave-uniform; denser blocks walk the registers as round 2 did)
-        unsigned khi[KPL], klo[KPL];
-        const int m = packed ? (n + 63) >> 6 : 0;
-#pragma unroll
-        for (int j = 0; j < KPL; ++j) {
-            const unsigned long long key = (j < m && lane + 64 * j < n) ? comp[lane + 64 * j] : 0ull;  // (0: not a positive double)
-            khi[j] = (unsigned)(key >> 32);
-            klo[j] = (unsigned)key;
+            for (int c = 0; c < WMAX; ++c) v[c] = -v[c];
         }
-        unsigned phi = 0, plo = 0;  // prefix found so far
-        int kk = (int)(a.q * (double)n);
-        bool done = false;  // (wave-uniform)
-#pragma unroll
-        for (int pass = 7; pass >= 0; --pass) {
-            if (done) continue;
-            const int sh = 8 * (pass & 3);  // digit position inside its dword (passes 7..4: high dword)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) hist[4 * lane + b] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // does a key still match the prefix above this digit?  (pass 7: every key does)
-            auto match = [&](unsigned kh, unsigned kl) -> bool {
-                if (pass >= 4) return pass == 7 || (kh >> (sh + 8)) == (phi >> (sh + 8));
-                return kh == phi && (pass == 3 || (kl >> (sh + 8)) == (plo >> (sh + 8)));
-            };
-            if (packed) {
-#pragma unroll
-                for (int j = 0; j < KPL; ++j)
-                    if (j < m && (khi[j] | klo[j]) != 0u && match(khi[j], klo[j]))
-                        atomicAdd(&hist[(int)(((pass >= 4 ? khi[j] : klo[j]) >> sh) & 255u)], 1);
-            } else {
-#pragma unroll
-                for (int i = 0; i < WMAX; ++i)
-                    if (v[i] > 0.0) {
-                        const unsigned long long key = (unsigned long long)__double_as_longlong(v[i]);
-                        const unsigned kh = (unsigned)(key >> 32), kl = (unsigned)key;
-                        if (match(kh, kl)) atomicAdd(&hist[(int)(((pass >= 4 ? kh : kl) >> sh) & 255u)], 1);
-                    }
+        int n = 0;
+    #pragma unroll
+        for (int c = 0; c < WMAX; ++c) {
+            const bool p = v[c] > 0.0;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(p);
+            const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            if (p && pos < kEdgeCap) comp[pos] = (unsigned long long)__double_as_longlong(v[c]);
+            n += __builtin_popcountll(bal);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double thr = 0.0;
+        if (n > 0) {
+            constexpr int KPL = kEdgeCap / 64;
+            const bool packed = n <= kEdgeCap;  // (wave-uniform; denser blocks walk the registers as round 2 did)
+            unsigned khi[KPL], klo[KPL];
+            const int m = packed ? (n + 63) >> 6 : 0;
+    #pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                const unsigned long long key = (j < m && lane + 64 * j < n) ? comp[lane + 64 * j] : 0ull;  // (0: not a positive double)
+                khi[j] = (unsigned)(key >> 32);
+                klo[j] = (unsigned)key;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
-            const int incl = wave_incl_scan(h0 + h1 + h2 + h3, lane);
-            const int excl = incl - (h0 + h1 + h2 + h3);
-            const bool mine = kk >= excl && kk < incl;
-            int b = 0, cum = excl;
-            if (kk >= cum + h0) {
-                cum += h0;
-                b = 1;
-                if (kk >= cum + h1) {
-                    cum += h1;
-                    b = 2;
-                    if (kk >= cum + h2) {
-                        cum += h2;
-                        b = 3;
-                    }
-                }
-            }
-            const int src = __builtin_ctzll(__builtin_amdgcn_ballot_w64(mine));  // exactly one lane holds k
-            const unsigned digit = (unsigned)__shfl(4 * lane + b, src);
-            const int cnt = __shfl(b == 0 ? h0 : (b == 1 ? h1 : (b == 2 ? h2 : h3)), src);
-            kk = __shfl(kk - cum, src);
-            if (pass >= 4)
-                phi |= digit << sh;
-            else
-                plo |= digit << sh;
-            __builtin_amdgcn_wave_barrier();  // everyone has read the histogram before it is cleared again
-            if (cnt == 1 && pass > 0) {  // one value left under this prefix: it is the k-th smallest
-                // (a key matches "through this digit": the match of the NEXT pass, evaluated now)
-                auto through = [&](unsigned kh, unsigned kl) -> bool {
-                    if (pass >= 4) return (kh >> sh) == (phi >> sh);
-                    return kh == phi && (kl >> sh) == (plo >> sh);
+            unsigned phi = 0, plo = 0;  // prefix found so far
+            int kk = (int)(a.q * (double)n);
+            bool done = false;  // (wave-uniform)
+    #pragma unroll
+            for (int pass = 7; pass >= 0; --pass) {
+                if (done) continue;
+                const int sh = 8 * (pass & 3);  // digit position inside its dword (passes 7..4: high dword)
+    #pragma unroll
+                for (int b = 0; b < 4; ++b) hist[4 * lane + b] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // does a key still match the prefix above this digit?  (pass 7: every key does)
+                auto match = [&](unsigned kh, unsigned kl) -> bool {
+                    if (pass >= 4) return pass == 7 || (kh >> (sh + 8)) == (phi >> (sh + 8));
+                    return kh == phi && (pass == 3 || (kl >> (sh + 8)) == (plo >> (sh + 8)));
                 };
-                unsigned fh = 0, fl = 0;
                 if (packed) {
-#pragma unroll
+    #pragma unroll
                     for (int j = 0; j < KPL; ++j)
-                        if (j < m && (khi[j] | klo[j]) != 0u && through(khi[j], klo[j])) {
-                            fh = khi[j];
-                            fl = klo[j];
-                        }
+                        if (j < m && (khi[j] | klo[j]) != 0u && match(khi[j], klo[j]))
+                            atomicAdd(&hist[(int)(((pass >= 4 ? khi[j] : klo[j]) >> sh) & 255u)], 1);
                 } else {
-#pragma unroll
+    #pragma unroll
                     for (int i = 0; i < WMAX; ++i)
                         if (v[i] > 0.0) {
                             const unsigned long long key = (unsigned long long)__double_as_longlong(v[i]);
-                            if (through((unsigned)(key >> 32), (unsigned)key)) {
-                                fh = (unsigned)(key >> 32);
-                                fl = (unsigned)key;
-                            }
+                            const unsigned kh = (unsigned)(key >> 32), kl = (unsigned)key;
+                            if (match(kh, kl)) atomicAdd(&hist[(int)(((pass >= 4 ? kh : kl) >> sh) & 255u)], 1);
                         }
                 }
-                const int owner = __builtin_ctzll(__builtin_amdgcn_ballot_w64((fh | fl) != 0u));
-                phi = (unsigned)__shfl((int)fh, owner);
-                plo = (unsigned)__shfl((int)fl, owner);
-                done = true;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+                const int incl = wave_incl_scan(h0 + h1 + h2 + h3, lane);
+                const int excl = incl - (h0 + h1 + h2 + h3);
+                const bool mine = kk >= excl && kk < incl;
+                int b = 0, cum = excl;
+                if (kk >= cum + h0) {
+                    cum += h0;
+                    b = 1;
+                    if (kk >= cum + h1) {
+                        cum += h1;
+                        b = 2;
+                        if (kk >= cum + h2) {
+                            cum += h2;
+                            b = 3;
+                        }
+                    }
+                }
+                const int src = __builtin_ctzll(__builtin_amdgcn_ballot_w64(mine));  // exactly one lane holds k
+                const unsigned digit = (unsigned)__shfl(4 * lane + b, src);
+                const int cnt = __shfl(b == 0 ? h0 : (b == 1 ? h1 : (b == 2 ? h2 : h3)), src);
+                kk = __shfl(kk - cum, src);
+                if (pass >= 4)
+                    phi |= digit << sh;
+                else
+                    plo |= digit << sh;
+                __builtin_amdgcn_wave_barrier();  // everyone has read the histogram before it is cleared again
+                if (cnt == 1 && pass > 0) {  // one value left under this prefix: it is the k-th smallest
+                    // (a key matches "through this digit": the match of the NEXT pass, evaluated now)
+                    auto through = [&](unsigned kh, unsigned kl) -> bool {
+                        if (pass >= 4) return (kh >> sh) == (phi >> sh);
+                        return kh == phi && (kl >> sh) == (plo >> sh);
+                    };
+                    unsigned fh = 0, fl = 0;
+                    if (packed) {
+    #pragma unroll
+                        for (int j = 0; j < KPL; ++j)
+                            if (j < m && (khi[j] | klo[j]) != 0u && through(khi[j], klo[j])) {
+                                fh = khi[j];
+                                fl = klo[j];
+                            }
+                    } else {
+    #pragma unroll
+                        for (int i = 0; i < WMAX; ++i)
+                            if (v[i] > 0.0) {
+                                const unsigned long long key = (unsigned long long)__double_as_longlong(v[i]);
+                                if (through((unsigned)(key >> 32), (unsigned)key)) {
+                                    fh = (unsigned)(key >> 32);
+                                    fl = (unsigned)key;
+                                }
+                            }
+                    }
+                    const int owner = __builtin_ctzll(__builtin_amdgcn_ballot_w64((fh | fl) != 0u));
+                    phi = (unsigned)__shfl((int)fh, owner);
+                    plo = (unsigned)__shfl((int)fl, owner);
+                    done = true;
+                }
+            }
+            const double tau = __longlong_as_double((long long)(((unsigned long long)phi << 32) | plo));
+            thr = tau > a.abst[e] ? tau : a.abst[e];
+        }
+        // ---- 3. threshold -> one mask per bin (bit c = frame c of the block) --------------------------------------
+        unsigned mlo = 0, mhi = 0;
+    #pragma unroll
+        for (int c = 0; c < WMAX; ++c) {
+            const unsigned bit = (n > 0 && v[c] > 0.0 && v[c] >= thr) ? 1u : 0u;
+            if (c < 32)
+                mlo |= bit << c;
+            else
+                mhi |= bit << (c - 32);
+        }
+        const unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
+        // ---- 4. spread along the orientation inside the block ------------------------------------------------------
+        unsigned long long r = m;
+        for (int k = 1; k <= a.spread; ++k) {
+            const int la = h + k * d0, lb = h - k * d0;
+            // (__shfl reads lane (index mod 64): out-of-range bins contribute nothing)
+            unsigned long long ua = ((unsigned long long)(unsigned)__shfl((int)(m >> 32), la & 63) << 32) | (unsigned)__shfl((int)m, la & 63);
+            unsigned long long ub = ((unsigned long long)(unsigned)__shfl((int)(m >> 32), lb & 63) << 32) | (unsigned)__shfl((int)m, lb & 63);
+            if (la < 0 || la >= H) ua = 0;
+            if (lb < 0 || lb >= H) ub = 0;
+            const int sh = k * d1;
+            if (sh < 64) {
+                r |= ua >> sh;            // bin[h + k d0][c + k d1]
+                r |= (ub << sh) & wmask;  // bin[h - k d0][c - k d1]
             }
         }
-        const double tau = __longlong_as_double((long long)(((unsigned long long)phi << 32) | plo));
-        thr = tau > a.abst[e] ? tau : a.abst[e];
+        masks[e * 64 + lane] = hon ? r : 0ull;
     }
-    // ---- 3. threshold -> one mask per bin (bit c = frame c of the block) --------------------------------------
-    unsigned mlo = 0, mhi = 0;
-#pragma unroll
-    for (int c = 0; c < WMAX; ++c) {
-        const unsigned bit = (n > 0 && v[c] > 0.0 && v[c] >= thr) ? 1u : 0u;
-        if (c < 32)
-            mlo |= bit << c;
-        else
-            mhi |= bit << (c - 32);
-    }
-    const unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
-    // ---- 4. spread along the orientation inside the block ------------------------------------------------------
-    const int d0 = pair == 0 ? 0 : (pair == 3 ? -1 : 1), d1 = pair == 1 ? 0 : 1;
-    const unsigned long long wmask = W >= 64 ? ~0ull : ((1ull << W) - 1ull);
-    unsigned long long r = m;
-    for (int k = 1; k <= a.spread; ++k) {
-        const int la = h + k * d0, lb = h - k * d0;
-        // (__shfl reads lane (index mod 64): out-of-range bins contribute nothing)
-        unsigned long long ua = ((unsigned long long)(unsigned)__shfl((int)(m >> 32), la & 63) << 32) | (unsigned)__shfl((int)m, la & 63);
-        unsigned long long ub = ((unsigned long long)(unsigned)__shfl((int)(m >> 32), lb & 63) << 32) | (unsigned)__shfl((int)m, lb & 63);
-        if (la < 0 || la >= H) ua = 0;
-        if (lb < 0 || lb >= H) ub = 0;
-        const int sh = k * d1;
-        if (sh < 64) {
-            r |= ua >> sh;            // bin[h + k d0][c + k d1]
-            r |= (ub << sh) & wmask;  // bin[h - k d0][c - k d1]
-        }
-    }
-    masks[e * 64 + lane] = hon ? r : 0ull;
+
     __syncthreads();
     // ---- 5. the kept frames, whole resident rows [frame][h * 8 + e]: lane = bin, wave w takes frames w, w + 8, ... ---
     const int groups = a.Dp >> 3;  // 8-byte groups of a row (the last one may be padding: zeros)
@@ -587,7 +596,7 @@ __global__ __launch_bounds__(512, WMAX <= 48 ? 4 : 2) void edge_block_bin_kernel
         unsigned long long me[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) me[q] = masks[q * 64 + lane];  // (0 for bins >= H)
-        for (int c = keep0 + e; c < W; c += 8) {
+        for (int c = keep0 + pair; c < W; c += 4) {
             unsigned lo = 0, hi = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -604,7 +613,7 @@ int launch_edge_bin(tsr_ctx *ctx, const EdgeArgs &a, int64_t n_items, size_t lds
 {
     TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_block_bin_kernel<WMAX>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(edge_block_bin_kernel<WMAX>, dim3((unsigned)n_items), dim3(512), lds, ctx->stream, a);
+    hipLaunchKernelGGL(edge_block_bin_kernel<WMAX>, dim3((unsigned)n_items), dim3(256), lds, ctx->stream, a);
     TSR_HIP(hipGetLastError());
     return TSR_OK;
 }
@@ -646,7 +655,7 @@ int tsr_launch_edge_blocks(tsr_ctx *ctx, const double *d_S, const uint8_t *d_mas
     a.out = d_out;
     const size_t hw = (size_t)H * block_length;
     if (H <= 64 && block_length <= 64 && (Dp >> 3) <= 64 && !g_edge_kernel_old) {  // one lane per frequency bin
-        const size_t lds_b = (size_t)8 * 64 * 8 + 8 * 256 * 4 + (size_t)8 * kEdgeCap * 8 + (size_t)(block_length + 3) * H * 8;
+        const size_t lds_b = (size_t)8 * 64 * 8 + 4 * 256 * 4 + (size_t)4 * kEdgeCap * 8 + (size_t)(block_length + 3) * H * 8;
         if (block_length <= 32) return launch_edge_bin<32>(ctx, a, n_items, lds_b);
         if (block_length <= 40) return launch_edge_bin<40>(ctx, a, n_items, lds_b);   // (the reference's default block length)
         if (block_length <= 48) return launch_edge_bin<48>(ctx, a, n_items, lds_b);
