@@ -262,3 +262,108 @@ int tsr_launch_exact_bank_mfma(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *c
     TSR_HIP(hipGetLastError());
     return TSR_OK;
 }
+
+// ---- isolated-window classification (get_train_data.py:836-922 over detect_float, compute_likelihood_linear_filter.pyx:178-219)
+// on the same matrix-core chains.  A window row is either a REAL frame of the binary corpus -- product w * x with x in
+// {0, 1}: exact, so fma(x, w, acc) is the reference's "round the product, then add" -- or a PADDING row holding the
+// background vector -- product rn(w * bgd[d]), precomputed (WB), added as fma(1, wb, acc).  One accumulator row is a PAIR of
+// consecutive positions of a window (the two frame replicas of the B fragments: column (m, 1) walks the window one frame
+// later through the same physical rows), a tile is 16 pairs that share their padding pattern -- physical rows
+// [k, k + r) of the pair are real, all others padding (the host buckets the pairs by (k, r)) -- so that at every tap row
+// the whole tile takes either its frames' bytes against W or the constant 1.0 against WB: one matrix instruction per
+// K-step, all sixteen columns at work.  The A operand is gathered per lane (lane (i, k) takes byte 4 n + k of row i's
+// frame: a 16-byte load per four K-steps, the sixteen rows of a tile are sixteen different frames); no planes, no LDS.
+namespace {
+// WB fragments of a call: the bank's W fragments times the background value of each element's feature, rounded once
+__global__ __launch_bounds__(256) void iso_wb_kernel(const f32x4 *__restrict__ wm, int64_t total4, int NK4, const float *__restrict__ bgd, int D,
+                                                     f32x4 *__restrict__ wb)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total4) return;
+    const int lane = (int)(idx & 63), k = lane >> 4, n4 = (int)((idx >> 6) % NK4);
+    const f32x4 w = wm[idx];
+    f32x4 o;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int d = 16 * n4 + 4 * u + k;
+        o[u] = d < D ? __fmul_rn(w[u], bgd[d]) : 0.0f;
+    }
+    wb[idx] = o;
+}
+
+__global__ __launch_bounds__(256) void iso_mfma_kernel(const uint8_t *__restrict__ X, int Dp, const tsr_iso_pair *__restrict__ pairs,
+                                                       const int32_t *__restrict__ tile_kr, int64_t n_units, int n_groups,
+                                                       const f32x4 *__restrict__ wm, const f32x4 *__restrict__ wb,
+                                                       const int64_t *__restrict__ gm_off, const int32_t *__restrict__ gm_rows,
+                                                       const int32_t *__restrict__ Lm, const float *__restrict__ cf, int M, int64_t NW,
+                                                       float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t unit = __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6));
+    if (unit >= n_units) return;
+    const int64_t tile = unit / n_groups;
+    const int g = (int)(unit - tile * n_groups);
+    const int i = lane & 15, kk = lane >> 4;
+    const int k0 = tile_kr[2 * tile], k1 = k0 + tile_kr[2 * tile + 1];  // physical rows [k0, k1) of every pair are real
+    const int64_t f0 = pairs[tile * 16 + i].f0;
+    const int NK4 = Dp >> 4;
+    const int rows = gm_rows[g];
+    const f32x4 *wg = wm + gm_off[g] + lane, *bg = wb + gm_off[g] + lane;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int sh = 8 * kk;
+    for (int tp = 0; tp < rows; ++tp) {
+        const int64_t fo = ((int64_t)tp * NK4) * 64;
+        if (tp >= k0 && tp < k1) {  // (wave-uniform) real frames against W
+            const uint4 *xr = reinterpret_cast<const uint4 *>(X + (f0 + tp) * (int64_t)Dp);
+            const f32x4 *wp = wg + fo;
+            for (int n4 = 0; n4 < NK4; ++n4) {
+                const uint4 x = xr[n4];
+                const f32x4 b = wp[(int64_t)n4 * 64];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32((float)((x.x >> sh) & 0xffu), b[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32((float)((x.y >> sh) & 0xffu), b[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32((float)((x.z >> sh) & 0xffu), b[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32((float)((x.w >> sh) & 0xffu), b[3], acc, 0, 0, 0);
+            }
+        } else {  // background rows: 1.0 against rn(w * bgd)
+            const f32x4 *bp = bg + fo;
+            for (int n4 = 0; n4 < NK4; ++n4) {
+                const f32x4 b = bp[(int64_t)n4 * 64];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, b[u], acc, 0, 0, 0);
+            }
+        }
+    }
+    // lane l holds rows 4 (l / 16) + r of column j = l % 16: template j & 7 of the group, position item + (j >> 3)
+    const int j = lane & 15, m = g * TSR_MG + (j & 7), rep = j >> 3;
+    if (m >= M) return;
+    const int L = Lm[m];
+    const float c = cf[m];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const tsr_iso_pair q = pairs[tile * 16 + 4 * kk + r];
+        const bool second = (q.left >> 30) & 1;
+        const int left = (q.left & 0x3fffffff) - rep;
+        if (q.item < 0 || (rep && !second)) continue;
+        out[(int64_t)m * NW + q.item + rep] = (L <= left ? acc[r] : 0.0f) + c;
+    }
+}
+}  // namespace
+
+int tsr_launch_isolated_mfma(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *d_X, int Dp, const float *d_bgd,
+                             const tsr_iso_pair *d_pairs, const int32_t *d_tile_kr, int64_t n_tiles, int64_t NW, void *d_wb_scratch,
+                             float *d_out)
+{
+    if (!bank->d_Wm || Dp != bank->wm_Dp || bank->wm_total4 <= 0) return TSR_ERR_UNSUPPORTED;
+    if (n_tiles <= 0) return TSR_OK;
+    const int NK4 = Dp >> 4;
+    f32x4 *wb = static_cast<f32x4 *>(d_wb_scratch);
+    hipLaunchKernelGGL(iso_wb_kernel, dim3((unsigned)((bank->wm_total4 + 255) / 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const f32x4 *>(bank->d_Wm), bank->wm_total4, NK4, d_bgd, (int)bank->D, wb);
+    const int64_t n_units = n_tiles * bank->n_groups;
+    hipLaunchKernelGGL(iso_mfma_kernel, dim3((unsigned)((n_units + 3) / 4)), dim3(256), 0, ctx->stream, d_X, Dp, d_pairs, d_tile_kr, n_units,
+                       (int)bank->n_groups, reinterpret_cast<const f32x4 *>(bank->d_Wm), (const f32x4 *)wb, bank->d_gm_off, bank->d_gm_rows,
+                       bank->d_L, bank->d_cf, (int)bank->M, NW, d_out);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+

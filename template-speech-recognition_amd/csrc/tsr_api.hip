@@ -454,6 +454,14 @@ static int bank_build_exact(tsr_ctx *ctx, tsr_bank *b)
     b->d_gm_off = n_gm;
     b->d_gm_rows = n_gr;
     b->wm_Dp = Dp;
+    b->wm_total4 = 0;
+    b->gm_off_h.clear();
+    b->gm_rows_h.clear();
+    if (mfma_ok) {
+        b->gm_off_h = gm_off;
+        b->gm_rows_h = gm_rows;
+        for (int g = 0; g < b->n_groups; ++g) b->wm_total4 = std::max<int64_t>(b->wm_total4, gm_off[g] + (int64_t)gm_rows[g] * NK4 * 64);
+    }
     dev_free(b->d_Wx);
     dev_free(b->d_gx_off);
     dev_free(b->d_gx_L);
@@ -1062,38 +1070,108 @@ TSR_API int tsr_corpus_classify_isolated(tsr_ctx *ctx, const tsr_bank *bank, con
         NW += n_valid[w];
         ends[(size_t)w] = NW;
     }
-    TSR_REQUIRE(NW < ((int64_t)1 << 31), "tsr_corpus_classify_isolated: too many positions");
-    std::vector<int64_t> it((size_t)NW * 3);
-    std::vector<int32_t> left((size_t)NW);
-    for (int64_t w = 0; w < W; ++w)
-        for (int32_t t = 0; t < n_valid[w]; ++t) {
-            const size_t i = (size_t)(starts[(size_t)w] + t);
-            it[i] = first[w] + t;
-            it[(size_t)NW + i] = real_lo[w];
-            it[(size_t)2 * NW + i] = real_hi[w];
-            left[i] = rows[w] - t;
-        }
+    TSR_REQUIRE(NW < ((int64_t)1 << 30), "tsr_corpus_classify_isolated: too many positions");
+    for (int64_t d = 0; d < bank->D; ++d) TSR_REQUIRE(std::isfinite(bgd[d]), "tsr_corpus_classify_isolated: background value %lld is not finite", (long long)d);
     TSR_HIP(hipSetDevice(ctx->device));
+    // the scores of every searched position: on the matrix cores where the bank has that form, this context's probe of the
+    // f32 chains matched (run here, before any scratch buffer of this call exists: it uses them itself) and the option
+    // does not ask for the vector kernel; else one lane per position
+    bool on_mfma = false;
+    if (bank->d_Wm && cp->Dp == bank->wm_Dp && ctx->opt_exact_kernel != TSR_EXACT_KERNEL_VALU) {
+        TSR_TRY(exact_mfma_probe(ctx));
+        on_mfma = ctx->exact_mfma_state > 0;
+    }
+    TSR_TRY(tsr_corpus_need_bytes(ctx, cp));
     void *d_all = nullptr, *d_win = nullptr, *d_res = nullptr, *d_items = nullptr, *d_bgd = nullptr;
     TSR_TRY(tsr_scratch(ctx, SLOT_OUT, (size_t)bank->M * NW * 4, &d_all));
     TSR_TRY(tsr_scratch(ctx, SLOT_AUX, (size_t)W * 16, &d_win));
     TSR_TRY(tsr_scratch(ctx, SLOT_AUX2, (size_t)W * 16, &d_res));
-    TSR_TRY(tsr_scratch(ctx, SLOT_W, (size_t)NW * 28, &d_items));
     TSR_TRY(tsr_scratch(ctx, SLOT_IN, (size_t)bank->D * 4, &d_bgd));
     int64_t *d_starts = (int64_t *)d_win, *d_ends = d_starts + W;
     int64_t *d_loc = (int64_t *)d_res;
     float *d_score = (float *)(d_loc + W);
     int32_t *d_tid = (int32_t *)(d_score + W);
-    int64_t *d_first = (int64_t *)d_items;
-    int32_t *d_left = (int32_t *)(d_first + 3 * NW);
     TSR_HIP(hipMemcpyAsync(d_bgd, bgd, (size_t)bank->D * 4, hipMemcpyHostToDevice, ctx->stream));
     TSR_HIP(hipMemcpyAsync(d_starts, starts.data(), (size_t)W * 8, hipMemcpyHostToDevice, ctx->stream));
     TSR_HIP(hipMemcpyAsync(d_ends, ends.data(), (size_t)W * 8, hipMemcpyHostToDevice, ctx->stream));
-    TSR_HIP(hipMemcpyAsync(d_first, it.data(), (size_t)NW * 24, hipMemcpyHostToDevice, ctx->stream));
-    TSR_HIP(hipMemcpyAsync(d_left, left.data(), (size_t)NW * 4, hipMemcpyHostToDevice, ctx->stream));
-    TSR_TRY(tsr_corpus_need_bytes(ctx, cp));
-    TSR_TRY(tsr_launch_isolated_windows(ctx, bank, cp->d_feats, cp->Dp, (const float *)d_bgd, d_first, d_first + NW,
-                                        d_first + 2 * NW, d_left, NW, (float *)d_all));
+    std::vector<tsr_iso_pair> tiles;   // (kept alive until the stream is synchronised below)
+    std::vector<int32_t> tile_kr;
+    std::vector<int64_t> it;
+    std::vector<int32_t> left;
+    if (on_mfma) {
+        // pairs of consecutive positions, bucketed by padding pattern: physical rows [k, k + r) of the pair are real
+        int RMAX = 1;
+        for (int32_t r : bank->gm_rows_h) RMAX = std::max(RMAX, (int)r);
+        const int NB = (RMAX + 1) * (RMAX + 1);
+        std::vector<int32_t> key;
+        std::vector<tsr_iso_pair> pr;
+        key.reserve((size_t)NW / 2 + (size_t)W);
+        pr.reserve((size_t)NW / 2 + (size_t)W);
+        std::vector<int64_t> cnt((size_t)NB + 1, 0);
+        for (int64_t w = 0; w < W; ++w)
+            for (int32_t t = 0; t < n_valid[w]; t += 2) {
+                const int64_t f0 = first[w] + t;
+                int k = (int)std::min<int64_t>(std::max<int64_t>(real_lo[w] - f0, 0), RMAX);
+                const int e = (int)std::min<int64_t>(std::max<int64_t>(real_hi[w] - f0, 0), RMAX);
+                const int r = std::max(e - k, 0);
+                if (r == 0) k = 0;
+                tsr_iso_pair q;
+                q.f0 = f0;
+                q.item = (int32_t)(starts[(size_t)w] + t);
+                q.left = (rows[w] - t) | (t + 1 < n_valid[w] ? (1 << 30) : 0);
+                pr.push_back(q);
+                key.push_back(k * (RMAX + 1) + r);
+                ++cnt[(size_t)(k * (RMAX + 1) + r)];
+            }
+        std::vector<int64_t> at((size_t)NB + 1, 0);   // first tile row of a bucket (buckets padded to whole tiles of 16 pairs)
+        int64_t n_rows = 0;
+        for (int b = 0; b < NB; ++b) {
+            at[(size_t)b] = n_rows;
+            n_rows += (cnt[(size_t)b] + 15) / 16 * 16;
+        }
+        tsr_iso_pair filler;
+        filler.f0 = 0;
+        filler.item = -1;
+        filler.left = 0;
+        tiles.assign((size_t)n_rows, filler);
+        tile_kr.assign((size_t)(n_rows / 16) * 2, 0);
+        std::vector<int64_t> put(at);
+        for (size_t i = 0; i < pr.size(); ++i) tiles[(size_t)put[(size_t)key[i]]++] = pr[i];
+        for (int b = 0; b < NB; ++b)
+            for (int64_t row = at[(size_t)b]; row < at[(size_t)b] + (cnt[(size_t)b] + 15) / 16 * 16; row += 16) {
+                tile_kr[(size_t)(row / 16) * 2] = b / (RMAX + 1);
+                tile_kr[(size_t)(row / 16) * 2 + 1] = b % (RMAX + 1);
+                for (int64_t x = row; x < row + 16; ++x)   // filler rows shadow the tile's first pair (its frames are loaded, nothing is stored)
+                    if (tiles[(size_t)x].item < 0) tiles[(size_t)x].f0 = tiles[(size_t)row].f0;
+            }
+        const int64_t n_tiles = n_rows / 16;
+        void *d_wb = nullptr;
+        TSR_TRY(tsr_scratch(ctx, SLOT_W, (size_t)n_rows * sizeof(tsr_iso_pair) + (size_t)n_tiles * 8 + 64, &d_items));
+        TSR_TRY(tsr_scratch(ctx, SLOT_RAW, (size_t)(bank->wm_total4 + 128) * 16, &d_wb));
+        tsr_iso_pair *d_pairs = (tsr_iso_pair *)d_items;
+        int32_t *d_kr = (int32_t *)(d_pairs + n_rows);
+        TSR_HIP(hipMemcpyAsync(d_pairs, tiles.data(), (size_t)n_rows * sizeof(tsr_iso_pair), hipMemcpyHostToDevice, ctx->stream));
+        TSR_HIP(hipMemcpyAsync(d_kr, tile_kr.data(), (size_t)n_tiles * 8, hipMemcpyHostToDevice, ctx->stream));
+        TSR_TRY(tsr_launch_isolated_mfma(ctx, bank, cp->d_feats, cp->Dp, (const float *)d_bgd, d_pairs, d_kr, n_tiles, NW, d_wb, (float *)d_all));
+    } else {
+        it.resize((size_t)NW * 3);
+        left.resize((size_t)NW);
+        for (int64_t w = 0; w < W; ++w)
+            for (int32_t t = 0; t < n_valid[w]; ++t) {
+                const size_t i = (size_t)(starts[(size_t)w] + t);
+                it[i] = first[w] + t;
+                it[(size_t)NW + i] = real_lo[w];
+                it[(size_t)2 * NW + i] = real_hi[w];
+                left[i] = rows[w] - t;
+            }
+        TSR_TRY(tsr_scratch(ctx, SLOT_W, (size_t)NW * 28, &d_items));
+        int64_t *d_first = (int64_t *)d_items;
+        int32_t *d_left = (int32_t *)(d_first + 3 * NW);
+        TSR_HIP(hipMemcpyAsync(d_first, it.data(), (size_t)NW * 24, hipMemcpyHostToDevice, ctx->stream));
+        TSR_HIP(hipMemcpyAsync(d_left, left.data(), (size_t)NW * 4, hipMemcpyHostToDevice, ctx->stream));
+        TSR_TRY(tsr_launch_isolated_windows(ctx, bank, cp->d_feats, cp->Dp, (const float *)d_bgd, d_first, d_first + NW,
+                                            d_first + 2 * NW, d_left, NW, (float *)d_all));
+    }
     TSR_TRY(tsr_launch_window_argmax(ctx, (const float *)d_all, NW, (int)bank->M, d_starts, d_ends, W, d_score, d_loc, d_tid));
     std::vector<int64_t> loc64((size_t)W);
     TSR_HIP(hipMemcpyAsync(score, d_score, (size_t)W * 4, hipMemcpyDeviceToHost, ctx->stream));

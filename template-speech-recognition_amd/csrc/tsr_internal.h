@@ -112,6 +112,9 @@ struct tsr_bank {
     int64_t *d_gm_off = nullptr;     // float4 offset of group g in d_Wm
     int32_t *d_gm_rows = nullptr;    // tap rows of group g in d_Wm: max(L_g) + 1 over the group's pair (2p, 2p + 1)
     int wm_Dp = 0;                   // resident row stride the fragments were laid out for
+    int64_t wm_total4 = 0;           // float4 elements of d_Wm (without its two fragments of read-ahead slack)
+    std::vector<int64_t> gm_off_h;   // host copies of d_gm_off / d_gm_rows
+    std::vector<int32_t> gm_rows_h;
     // device, fast path (built lazily by detect_mfma.hip): [0] two int8 limbs, [1] three, [2] bf16, [3] bf16 hi + lo,
     // [4] two int8 limbs with two taps folded into K (tap2_bank_kernel, narrow feature rows)
     void *fast[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -232,6 +235,16 @@ int tsr_launch_window_argmax(tsr_ctx *ctx, const float *d_all, int64_t stride, i
                              const int64_t *d_ends, int64_t W, float *d_score, int64_t *d_loc, int32_t *d_tid);
 int tsr_launch_float_windows(tsr_ctx *ctx, const tsr_bank *bank, const float *d_X, const int32_t *d_item_row,
                              const int32_t *d_item_left, int64_t NW, float *d_out);
+// Isolated-window classification on the matrix cores (detect_exact_mfma.hip): pairs of consecutive positions of a
+// window, 16 pairs of one padding pattern per tile.  TSR_ERR_UNSUPPORTED when the bank has no matrix-core form.
+struct tsr_iso_pair {   // one row of a tile: the positions item and item + 1 of one window
+    int64_t f0;         // stream frame of the first position's first row (may lie in front of the corpus: padding)
+    int32_t item;       // index of the first position in the item list (-1: filler row of a tile)
+    int32_t left;       // rows the window has left at the first position; bit 30: the second position exists
+};
+int tsr_launch_isolated_mfma(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *d_X, int Dp, const float *d_bgd,
+                             const tsr_iso_pair *d_pairs, const int32_t *d_tile_kr, int64_t n_tiles, int64_t NW, void *d_wb_scratch,
+                             float *d_out);
 int tsr_launch_isolated_windows(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *d_X, int Dp, const float *d_bgd,
                                 const int64_t *d_first, const int64_t *d_lo, const int64_t *d_hi,
                                 const int32_t *d_left, int64_t NW, float *d_out);

@@ -804,6 +804,31 @@ def test_classification_random_vs_oracle(mods, oracle):
             fn(*((E, None, f.copy(), 0, z[0], z[3], z[2], z[1], bank) + ((q,) if isolated else ())))
             for a, b in zip(batched, z):
                 assert np.array_equal(a[n, :len(f) - 1], b[0, :len(f) - 1]), (isolated, n)
+    # the isolated windows on the matrix cores (pairs of positions, tiles of one padding pattern) and through the
+    # one-lane-per-position vector kernel: the same triples, and a larger ragged case against the oracle on both
+    big = [synth.features(rng, T, q) for T in (200, 57, 140, 33, 96)]
+    bfl = []
+    for E in big:
+        b = [0]
+        while b[-1] < E.shape[0]:
+            b.append(min(E.shape[0], b[-1] + int(rng.integers(1, 30))))
+        bfl.append(np.array(b, np.int64))
+    res = {}
+    for name, opt in (("mfma", tsr_hip.TSR_OPT_AUTO), ("valu", tsr_hip.TSR_EXACT_KERNEL_VALU)):
+        with tsr_hip.default_ctx().option(tsr_hip.TSR_OPT_EXACT_KERNEL, opt):
+            res[name] = gtrd.get_classify_scores_E(big, bfl, bank, bgd=q, isolated=True)
+    for a, b in zip(res["mfma"], res["valu"]):
+        assert np.array_equal(a, b)
+    fresh = tsr_hip.Context(0)            # a context whose first exact work is this call: the probe runs inside it
+    assert fresh.get_option(tsr_hip.TSR_INFO_EXACT_MFMA) == 0
+    for a, b in zip(gtrd.get_classify_scores_E(big, bfl, bank, bgd=q, isolated=True, ctx=fresh), res["mfma"]):
+        assert np.array_equal(a, b)
+    assert fresh.get_option(tsr_hip.TSR_INFO_EXACT_MFMA) == 1
+    for n, (E, f) in enumerate(zip(big, bfl)):
+        z = [np.zeros((1, len(f)), dt) for dt in (np.float32, np.int16, np.uint16, np.uint16)]
+        oracle.compute_isolated_classification_E(E, None, f.copy(), 0, z[0], z[3], z[2], z[1], bank, q)
+        for a, b in zip(res["mfma"], z):
+            assert np.array_equal(a[n, :len(f) - 1], b[0, :len(f) - 1]), n
     ew, ws, we, pad = gtrd.get_isolated_classify_windows(utts[0], None, fl[0].copy(), q, bank)
     sc, pos, tid = tsr_hip.Bank(bank).classify_float_windows(ew, we.astype(np.int64) - ws)
     ref = gtrd.get_classify_scores_E(utts[:1], fl[:1], bank, bgd=q, isolated=True)

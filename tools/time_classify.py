@@ -52,8 +52,17 @@ for _ in range(4):
     ctx.sync(); t0 = time.perf_counter()
     corpus.classify_isolated(bank, q, *cat)
     best = min(best, time.perf_counter() - t0)
+res_m = corpus.classify_isolated(bank, q, *cat)
 print("isolated windows (virtual, resident corpus): %d windows, %d positions: window geometry on the host %.1f ms, "
       "item tables + kernels + download %.2f ms" % (len(cat[0]), int(cat[4].sum()), t_glue * 1e3, best * 1e3))
+with ctx.option(tsr_hip.TSR_OPT_EXACT_KERNEL, tsr_hip.TSR_EXACT_KERNEL_VALU):   # the one-lane-per-position vector kernel
+    best_v = 1e9
+    for _ in range(4):
+        ctx.sync(); t0 = time.perf_counter()
+        res_v = corpus.classify_isolated(bank, q, *cat)
+        best_v = min(best_v, time.perf_counter() - t0)
+print("  the same through the vector kernel (TSR_EXACT_KERNEL_VALU): %.2f ms; results identical: %s"
+      % (best_v * 1e3, all(np.array_equal(a, b) for a, b in zip(res_m, res_v))))
 if "--materialised" in sys.argv:
     t0 = time.perf_counter()
     allw, nv = [], []
