@@ -1103,26 +1103,17 @@ TSR_API int tsr_corpus_classify_isolated(tsr_ctx *ctx, const tsr_bank *bank, con
         int RMAX = 1;
         for (int32_t r : bank->gm_rows_h) RMAX = std::max(RMAX, (int)r);
         const int NB = (RMAX + 1) * (RMAX + 1);
-        std::vector<int32_t> key;
-        std::vector<tsr_iso_pair> pr;
-        key.reserve((size_t)NW / 2 + (size_t)W);
-        pr.reserve((size_t)NW / 2 + (size_t)W);
+        auto pattern = [&](int64_t w, int32_t t) -> int {   // bucket of the pair that starts at position t of window w
+            const int64_t f0 = first[w] + t;
+            int k = (int)std::min<int64_t>(std::max<int64_t>(real_lo[w] - f0, 0), RMAX);
+            const int e = (int)std::min<int64_t>(std::max<int64_t>(real_hi[w] - f0, 0), RMAX);
+            const int r = std::max(e - k, 0);
+            if (r == 0) k = 0;
+            return k * (RMAX + 1) + r;
+        };
         std::vector<int64_t> cnt((size_t)NB + 1, 0);
         for (int64_t w = 0; w < W; ++w)
-            for (int32_t t = 0; t < n_valid[w]; t += 2) {
-                const int64_t f0 = first[w] + t;
-                int k = (int)std::min<int64_t>(std::max<int64_t>(real_lo[w] - f0, 0), RMAX);
-                const int e = (int)std::min<int64_t>(std::max<int64_t>(real_hi[w] - f0, 0), RMAX);
-                const int r = std::max(e - k, 0);
-                if (r == 0) k = 0;
-                tsr_iso_pair q;
-                q.f0 = f0;
-                q.item = (int32_t)(starts[(size_t)w] + t);
-                q.left = (rows[w] - t) | (t + 1 < n_valid[w] ? (1 << 30) : 0);
-                pr.push_back(q);
-                key.push_back(k * (RMAX + 1) + r);
-                ++cnt[(size_t)(k * (RMAX + 1) + r)];
-            }
+            for (int32_t t = 0; t < n_valid[w]; t += 2) ++cnt[(size_t)pattern(w, t)];
         std::vector<int64_t> at((size_t)NB + 1, 0);   // first tile row of a bucket (buckets padded to whole tiles of 16 pairs)
         int64_t n_rows = 0;
         for (int b = 0; b < NB; ++b) {
@@ -1136,7 +1127,13 @@ TSR_API int tsr_corpus_classify_isolated(tsr_ctx *ctx, const tsr_bank *bank, con
         tiles.assign((size_t)n_rows, filler);
         tile_kr.assign((size_t)(n_rows / 16) * 2, 0);
         std::vector<int64_t> put(at);
-        for (size_t i = 0; i < pr.size(); ++i) tiles[(size_t)put[(size_t)key[i]]++] = pr[i];
+        for (int64_t w = 0; w < W; ++w)
+            for (int32_t t = 0; t < n_valid[w]; t += 2) {
+                tsr_iso_pair &q = tiles[(size_t)put[(size_t)pattern(w, t)]++];
+                q.f0 = first[w] + t;
+                q.item = (int32_t)(starts[(size_t)w] + t);
+                q.left = (rows[w] - t) | (t + 1 < n_valid[w] ? (1 << 30) : 0);
+            }
         for (int b = 0; b < NB; ++b)
             for (int64_t row = at[(size_t)b]; row < at[(size_t)b] + (cnt[(size_t)b] + 15) / 16 * 16; row += 16) {
                 tile_kr[(size_t)(row / 16) * 2] = b / (RMAX + 1);

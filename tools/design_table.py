@@ -106,12 +106,13 @@ if us4:
                  "%s Tflop/s = %s of the int8 peak" % (f(338e9 / us4 / 1e6, "%.0f"), f(338e9 / us4 / 1e6 / 5000, "%.3f")), "as config 2"))
 # ---- next rows ----------------------------------------------------------------------------------------------------
 for csvn, needle, label, work, alg, bound in (
-        ("classify_kernel_stats.csv", "isolated_windows_kernel", "`isolated_windows_kernel`", "133 k positions x 8 templates (N1)", "24.5 Gflop in `detect_float`'s order", "vector instructions (f32 chains in the reference's order)"),
-        ("edges_kernel_stats.csv", "edge_block_bin_kernel", "`edge_block_bin_kernel<40>`", "1000 spectrograms -> edge corpus (N3)", "72 MB in, 74 MB out", "instruction issue (stencil + select per block); round 2: 445 us"),
+        ("classify_kernel_stats.csv", "iso_mfma_kernel", "`iso_mfma_kernel` (isolated windows on the f32 matrix cores)", "133 k positions x 8 templates (N1)", "24.5 Gflop in `detect_float`'s order", "matrix pipe ~50 % busy: half-empty tiles of rare padding patterns, per-lane operand gathers"),
+        ("classify_kernel_stats.csv", "isolated_windows_kernel", "`isolated_windows_kernel` (vector kernel: `TSR_EXACT_KERNEL_VALU`, banks without the matrix-core form)", "133 k positions x 8 templates (N1)", "24.5 Gflop in `detect_float`'s order", "vector instructions (f32 chains in the reference's order)"),
+        ("edges_kernel_stats.csv", "edge_block_bin_kernel", "`edge_block_bin_kernel<40>`", "1000 spectrograms -> edge corpus (N3)", "72 MB in, 74 MB out", "instruction issue (stencil + two selects per wave); round 2: 445 us"),
         ("edges_kernel_stats.csv", "edge_block_wave_kernel", "`edge_block_wave_kernel<32>`", "1000 spectrograms -> edge corpus (N3)", "72 MB in, 74 MB out", "the per-block radix select")):
     u, c = kavg(csvn, needle)
     if u:
-        extra = ("%s Tflop/s" % f(24.5e9 / u / 1e6, "%.1f")) if "isolated" in needle else ("%s TB/s" % f(146e6 / u / 1e6, "%.2f"))
+        extra = ("%s Tflop/s" % f(24.5e9 / u / 1e6, "%.1f")) if ("isolated" in needle or "iso_" in needle) else ("%s TB/s" % f(146e6 / u / 1e6, "%.2f"))
         rows.append((label, work, alg, "%s us rocprofv3 average of %d (`%s_%s`)" % (f(u), c, R, csvn), extra, bound))
 out = ["| kernel | workload | algorithmic work per launch | time (source) | achieved | bound by |", "|---|---|---|---|---|---|"]
 out += ["| " + " | ".join(r) + " |" for r in rows]
