@@ -25,13 +25,22 @@
 // GEMM shape.  The resident corpus is a byte stream with row stride Dp (a multiple of 16) and
 // E = 8 edge bytes per frequency bin, i.e. a stream of 8-byte "positions", S = Dp/8 per frame.
 // For the patch at position p, cell (i, j, z) is byte (p + i*S + j)*8 + z: the same offset for
-// every location, so 32 consecutive positions form the N dimension of one MFMA (B operand:
-// lane n reads 16 bytes = 2 bins x 8 edges at its own position), the K dimension runs over
-// (patch row i, bin pair c) and the M dimension over the parts (A operand: weights, held in
-// registers for the life of the workgroup).  Positions whose bin index exceeds X1 - P1 are
-// computed and dropped (41 of 46 are live for 45 bins).  The result layout puts the parts of
-// one location into the registers of one lane (and its partner lane + 32), so the argmax is
-// per-lane VALU work: a packed key (I_k << 6 | k), v_max + v_med3 per part.
+// every location, so 32 locations form the N dimension of one MFMA (B operand: lane n reads
+// 16 bytes = 2 bins x 8 edges of its own location's patch), the K dimension runs over PAIRS OF
+// PATCH BINS (bins 2g and 2g+1 of the P0*P1 in row-major order, wherever they lie: the two
+// 8-byte halves of a lane's operand are separate LDS reads) and the M dimension over the parts
+// (A operand: weights, held in registers for the life of the workgroup).  A tile is 32
+// consecutive LIVE locations of the chunk (bins beyond X1 - P1 are never computed).  The result
+// layout puts the parts of one location into the registers of one lane (and its partner lane
+// + 32), so the argmax is per-lane VALU work on a packed key (I_k << 6 | k): the staged bytes
+// are 0 / 64 instead of 0 / 1 and the accumulator of the low limb starts at (B_k << 6 | k), so
+// that key = (high limb sum << 8) + low limb sum -- one instruction -- then v_med3 + v_max.
+//
+// Schedule.  A wave alternates between the two M-tiles (32 part slots each) with two
+// accumulator pairs: while the matrix instructions of one half-tile issue, the keys of the
+// previous half-tile are reduced (and, behind the second M-tile, the location is finished),
+// dealt out between the K-block steps -- the vector work rides in the shadow of the wave's own
+// matrix instructions instead of alternating with them.
 //
 // Frames are staged through LDS in chunks of CH frames (+ P0 - 1 rows of overlap); chunks are
 // handed out by an atomic counter (persistent workgroups, 2 per CU).
@@ -51,18 +60,17 @@ constexpr int kWaves = kWG / 64;
 constexpr int kPad = 256;             // zeroed bytes behind the staged rows (over-read of the last bin pairs)
 constexpr int kVInv = -(1 << 25) + 1024;  // value of the empty part slots: below every real score
 constexpr int kVMax = 1 << 24;            // |I_k| bound of the real slots
+constexpr int kOnesKey = kVInv * 64 + 63; // start value of slot 63, the row of ones (edge count)
 
 struct PmArgs {
     const uint8_t *X;  // resident corpus [P][Dp]
     int64_t P;
-    int Dp, S, N1, P0, CH, nchunks;
+    int Dp, S, N1, P0, P1, CH, nchunks;
     const int32_t *utt_end;
     const i32x4 *Wq;    // [mt 2][kb NKB][limb 2][lane 64]
     const int32_t *Kc;  // [half 2][mt 2][r 16]: (B_m << 6) | m
-    int G1, NG;         // K-groups: (patch row i, bin pair c), g = i*G1 + c, NG of them
     int K;
     unsigned threshold;
-    int fast;
     float o0_const, o0_slack;  // code_parts_fast: slot 0 in units (see host prep)
     int n_inv;                 // empty part slots (incl. the row of ones)
     int *work;                 // [0] chunk counter, [1] list length
@@ -71,16 +79,9 @@ struct PmArgs {
     uint32_t *list;            // [n][2]: location, full (slot 0 of code_parts_fast in play)
 };
 
-// (a << sh) + b in one instruction (hipcc splits the key of a part slot, (hi << 14) + (lo << 6) + base, into two shifts
-// and a three-operand add: three instructions where two do)
-template <int SH>
-__device__ __forceinline__ int lshl_add(int a, int b)
-{
-    int d;
-    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(SH), "v"(b));
-    return d;
-}
-
+// NOTE: nothing that reads an accumulator of a matrix instruction may be inline asm -- the compiler's hazard
+// recogniser does not count the wait states between a v_mfma and an asm statement that reads its result (a
+// one-K-block build read the registers two cycles after the issue and got the old values); plain C++ is covered.
 __device__ __forceinline__ int med3(int a, int b, int c)
 {
     int d;
@@ -88,7 +89,8 @@ __device__ __forceinline__ int med3(int a, int b, int c)
     return d;
 }
 
-template <int NKB>
+// FAST: code_parts_fast's slot 0 (the sum of all part scores) is tracked as well.
+template <int NKB, bool FAST>
 __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -108,17 +110,42 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int l = 0; l < 2; ++l) W[mt][kb][l] = a.Wq[((mt * NKB + kb) * 2 + l) * 64 + lane];
-    int boff[NKB];
+    int boff[NKB][2];  // byte offsets of this lane's two patch bins of K-block kb (padding bins: weights are 0)
+    const int nbins = a.P0 * a.P1;
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {  // byte offset of this lane's K-group inside the patch (padding groups: weights are 0)
-        const int g = 2 * kb + half;
-        boff[kb] = g < a.NG ? ((g / a.G1) * a.S + 2 * (g % a.G1)) * 8 : 0;
-    }
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = 2 * (2 * kb + half) + h;
+            boff[kb][h] = q < nbins ? ((q / a.P1) * a.S + q % a.P1) * 8 : 0;
+        }
     if (tid < 64) kcl[tid] = a.Kc[tid];
+    const i32x16 *const kc0 = reinterpret_cast<const i32x16 *>(kcl + (half * 2 + 0) * 16);
+    const i32x16 *const kc1 = reinterpret_cast<const i32x16 *>(kcl + (half * 2 + 1) * 16);
 
     const int64_t body = a.P * (int64_t)a.Dp;
-    const int ntiles = a.CH * a.S / 32;
-    const float invS = 1.0f / (float)a.S;
+    const int nloc = a.CH * a.N1;  // live locations of a chunk, frame-major
+    const int ntiles = (nloc + 31) / 32;
+    const float invN1 = 1.0f / (float)a.N1;
+    // frame (inside the chunk) and bin of this lane's location of a tile; false past the chunk's last location
+    auto locate = [&](int tile, int &fl, int &j) -> bool {
+        const int ll = tile * 32 + n;
+        fl = (int)((float)ll * invN1);
+        j = ll - fl * a.N1;
+        if (j < 0) {
+            --fl;
+            j += a.N1;
+        } else if (j >= a.N1) {
+            ++fl;
+            j -= a.N1;
+        }
+        return ll < nloc;
+    };
+    auto patch_addr = [&](int tile) -> const uint8_t * {
+        int fl, j;
+        const bool ok = locate(tile, fl, j);
+        return rows + (ok ? (fl * a.S + j) * 8 : 0);
+    };
 
     for (;;) {
         __syncthreads();  // previous chunk fully consumed (and kcl visible the first time)
@@ -127,93 +154,53 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
         const int chunk = chunkl[0];
         if (chunk >= a.nchunks) break;  // uniform: every wave leaves together
         const int64_t f0 = (int64_t)chunk * a.CH;
-        {  // stage the chunk: a straight copy of (CH + P0 - 1) rows, zeros behind the corpus
+        {  // stage the chunk: (CH + P0 - 1) rows with every byte x 64, zeros behind the corpus
             const int64_t g0 = f0 * a.Dp;
             for (int off = tid * 16; off < row_bytes + kPad; off += kWG * 16) {
                 i32x4 v = {0, 0, 0, 0};
                 if (off < row_bytes && g0 + off + 16 <= body) v = *reinterpret_cast<const i32x4 *>(a.X + g0 + off);
-                *reinterpret_cast<i32x4 *>(rows + off) = v;
+                *reinterpret_cast<i32x4 *>(rows + off) = v << 6;  // bytes are 0 / 1: no carry between them
             }
             if (tid < a.CH) uendl[tid] = (f0 + tid < a.P) ? a.utt_end[f0 + tid] : 0;
         }
         __syncthreads();
 
-        for (int tile = wave; tile < ntiles; tile += kWaves) {
-            const int lp = tile * 32 + n;  // local position of this lane's location
-            const uint8_t *xa = rows + lp * 8;
-            // One M-tile (32 part slots) at a time, so that only two limb accumulators are live; the
-            // B fragments of a pass are all requested up front (one LDS latency per pass) and read
-            // again for the second M-tile (cheap next to 16 MFMAs).  Each of this lane's 32 slots
-            // yields a packed key (I << 6 | slot); best and second best are tracked per lane.
-            int best = INT32_MIN, second = INT32_MIN, cnt_own = 0;
-            float vsum = 0.0f;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                i32x16 acc[2] = {};
-                i32x4 bf[NKB];
-#pragma unroll
-                for (int kb = 0; kb < NKB; ++kb) {
-                    const i32x2 b0 = *reinterpret_cast<const i32x2 *>(xa + boff[kb]);
-                    const i32x2 b1 = *reinterpret_cast<const i32x2 *>(xa + boff[kb] + 8);
-                    bf[kb] = (i32x4){b0.x, b0.y, b1.x, b1.y};
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-                    for (int l = 0; l < 2; ++l)
-                        acc[l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(W[mt][kb][l], bf[kb], acc[l], 0, 0, 0);
-                // keep the two M-tiles apart in the schedule (one accumulator pair live: the weights
-                // leave no room for two); the SIMD's other wave fills the gaps
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const i32x4 kc = *reinterpret_cast<const i32x4 *>(kcl + (half * 2 + mt) * 16 + r4 * 4);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int key = lshl_add<14>(acc[1][r4 * 4 + c], lshl_add<6>(acc[0][r4 * 4 + c], kc[c]));
-                        second = med3(best, second, key);
-                        best = max(best, key);
-                        if (a.fast) vsum += (float)(key >> 6);
-                    }
-                }
-                if (mt == 1) cnt_own = acc[0][15];  // the row of ones is slot 63: half 1, mt 1, r 15
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        int best = INT32_MIN, second = INT32_MIN;
+        float vsum = 0.0f;
+        auto slot = [&](const i32x16 (&acc)[2], int i) {
+            const int key = (int)(((unsigned)acc[1][i] << 8) + (unsigned)acc[0][i]);  // one v_lshl_add_u32
+            second = med3(best, second, key);
+            best = max(best, key);
+            if (FAST) vsum += (float)(key >> 6);
+        };
+        // everything behind the second M-tile of tile `tile`: margin test, list or id
+        auto finish = [&](int tile, int cnt_own) {
             const int obest = __shfl_xor(best, 32), osecond = __shfl_xor(second, 32);
-            const unsigned count = (unsigned)__shfl(cnt_own, n + 32);
+            const unsigned count = (unsigned)__shfl(cnt_own, n + 32);  // the row of ones is slot 63: half 1, mt 1, r 15
             const int mbest = max(best, obest);
             const int msecond = max(min(best, obest), max(second, osecond));
             const int vbest = mbest >> 6;
             const int window = (int)count + 2;
-            // where is this location?
-            int fl = (int)((float)lp * invS);
-            int j = lp - fl * a.S;
-            if (j < 0) {
-                --fl;
-                j += a.S;
-            } else if (j >= a.S) {
-                ++fl;
-                j -= a.S;
-            }
+            int fl, j;
+            const bool ok = locate(tile, fl, j);
             const int64_t f = f0 + fl;
-            const bool live = j < a.N1 && f < a.P && f + a.P0 <= (int64_t)uendl[fl];
+            const bool live = ok && f < a.P && f + a.P0 <= (int64_t)uendl[ok ? fl : 0];
             const bool coded = count >= a.threshold;
             bool flag = live && coded && (vbest - (msecond >> 6) <= window);
             bool full = false;
-            if (a.fast) {
-                vsum += __shfl_xor(vsum, 32);
+            if (FAST) {
+                const float vs = vsum + __shfl_xor(vsum, 32);
                 // slot 0 = sum_k (S_k - 1) in units, pushed up by its error bound
-                const float o0 = vsum - (float)a.n_inv * (float)kVInv - (float)count + a.o0_const +
+                const float o0 = vs - (float)a.n_inv * (float)kVInv - (float)count + a.o0_const +
                                  (float)a.K * (0.5f * (float)count + 1.0f) + a.o0_slack;
                 full = live && coded && o0 >= (float)(vbest - window);
                 flag = flag || full;
             }
             const int64_t loc = f * a.N1 + j;
             if (flag && half == 0) {  // rare: hand the location to the f64 re-evaluation
-                const int slot = atomicAdd(a.work + 1, 1);
-                a.list[(size_t)slot * 2] = (uint32_t)loc;
-                a.list[(size_t)slot * 2 + 1] = full ? 1u : 0u;
+                const int sl = atomicAdd(a.work + 1, 1);
+                a.list[(size_t)sl * 2] = (uint32_t)loc;
+                a.list[(size_t)sl * 2 + 1] = full ? 1u : 0u;
             }
             if (live && half == 0 && !flag) {
                 const int id = coded ? (mbest & 63) + 1 : 0;
@@ -222,6 +209,73 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
                 else
                     a.argmax[loc] = id;
             }
+        };
+
+        // Half-tile pipeline: step A = M-tile 0 of a tile into accA (while the keys of the previous tile's M-tile 1
+        // are reduced out of accB and that tile is finished), step B = M-tile 1 into accB (while accA's keys are
+        // reduced and the operands of the wave's next tile are fetched).  Each low-limb accumulator is re-armed with
+        // its start keys straight from LDS as soon as its last key has been taken.
+        constexpr int SL = NKB > 3 ? NKB - 2 : NKB;  // step A: K-block steps that carry keys (the finish follows them)
+        i32x16 accA[2], accB[2];
+        i32x4 bf[NKB];
+        int tile = wave;
+        if (tile < ntiles) {
+            const uint8_t *xa = patch_addr(tile);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const i32x2 b0 = *reinterpret_cast<const i32x2 *>(xa + boff[kb][0]);
+                const i32x2 b1 = *reinterpret_cast<const i32x2 *>(xa + boff[kb][1]);
+                bf[kb] = (i32x4){b0.x, b0.y, b1.x, b1.y};
+            }
+            accA[0] = *kc0;
+            accB[0] = *kc1;
+        }
+        bool have_prev = false;
+        for (; tile < ntiles; tile += kWaves) {
+            // ---- step A
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                accA[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(W[0][kb][1], bf[kb], kb ? accA[1] : (i32x16){}, 0, 0, 0);
+                accA[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(W[0][kb][0], bf[kb], accA[0], 0, 0, 0);
+                if (have_prev) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (e * SL / 16 == kb) slot(accB, e);
+                    if (kb == (SL < NKB ? SL : NKB - 1)) {
+                        const int cnt_own = (accB[0][15] - kOnesKey) >> 6;
+                        accB[0] = *kc1;
+                        finish(tile - kWaves, cnt_own);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- step B
+            best = INT32_MIN;
+            second = INT32_MIN;
+            vsum = 0.0f;
+            const bool more = tile + kWaves < ntiles;
+            const uint8_t *xn = patch_addr(more ? tile + kWaves : tile);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                accB[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(W[1][kb][1], bf[kb], kb ? accB[1] : (i32x16){}, 0, 0, 0);
+                accB[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(W[1][kb][0], bf[kb], accB[0], 0, 0, 0);
+                {  // this K-block's operand of the wave's next tile (the last tile fetches itself again)
+                    const i32x2 b0 = *reinterpret_cast<const i32x2 *>(xn + boff[kb][0]);
+                    const i32x2 b1 = *reinterpret_cast<const i32x2 *>(xn + boff[kb][1]);
+                    bf[kb] = (i32x4){b0.x, b0.y, b1.x, b1.y};
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (e * NKB / 16 == kb) slot(accA, e);
+                if (kb == NKB - 1) accA[0] = *kc0;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            have_prev = true;
+        }
+        if (have_prev) {  // the wave's last tile: nothing left to overlap
+#pragma unroll
+            for (int e = 0; e < 16; ++e) slot(accB, e);
+            finish(tile - kWaves, (accB[0][15] - kOnesKey) >> 6);
         }
     }
 }
@@ -308,15 +362,20 @@ __global__ __launch_bounds__(64 * kRcWaves) void code_parts_recheck_kernel(
     }
 }
 
-template <int NKB>
-int launch_nkb(tsr_ctx *ctx, const PmArgs &a, size_t lds)
+template <int NKB, bool FAST>
+int launch_nkb2(tsr_ctx *ctx, const PmArgs &a, size_t lds)
 {
-    TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(code_parts_mfma_kernel<NKB>),
+    TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(code_parts_mfma_kernel<NKB, FAST>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = std::min(a.nchunks, 2 * std::max(ctx->cus, 1));
-    hipLaunchKernelGGL(code_parts_mfma_kernel<NKB>, dim3((unsigned)grid), dim3(kWG), lds, ctx->stream, a);
+    hipLaunchKernelGGL((code_parts_mfma_kernel<NKB, FAST>), dim3((unsigned)grid), dim3(kWG), lds, ctx->stream, a);
     TSR_HIP(hipGetLastError());
     return TSR_OK;
+}
+template <int NKB>
+int launch_nkb(tsr_ctx *ctx, const PmArgs &a, size_t lds, bool fast)
+{
+    return fast ? launch_nkb2<NKB, true>(ctx, a, lds) : launch_nkb2<NKB, false>(ctx, a, lds);
 }
 
 }  // namespace
@@ -343,8 +402,8 @@ int tsr_parts_mfma_prepare(tsr_ctx *ctx, tsr_parts *p, const double *lp, const d
     const int64_t K = p->K, P0 = p->P0, P1 = p->P1, E = p->E, Q = P0 * P1 * E;
     if (E != 8) return no("E != 8 edge bytes per bin");
     if (K > 63) return no("more than 63 parts");
-    const int64_t G1 = (P1 + 1) / 2, NG = P0 * G1;
-    if (NG > 16) return no("patch larger than 16 K-groups (P0 * ceil(P1/2) > 16)");
+    const int64_t NB = P0 * P1, NG = (NB + 1) / 2;  // K-groups: pairs of patch bins in row-major order
+    if (NG > 16) return no("patch larger than 32 bins");
     const int nkb = (int)((NG + 1) / 2);
     double maxd = 0.0, maxabs = 0.0;
     for (int64_t i = 0; i < K * Q; ++i) {
@@ -379,13 +438,12 @@ int tsr_parts_mfma_prepare(tsr_ctx *ctx, tsr_parts *p, const double *lp, const d
     for (int m = 0; m < 64; ++m) {
         const int mt = m / 32, mr = m % 32;
         for (int64_t g = 0; g < NG; ++g) {
-            const int64_t ip = g / G1, c = g % G1;
             const int kb = (int)(g / 2), kg = (int)(g % 2);
             const int lane = kg * 32 + mr;
             for (int t = 0; t < 16; ++t) {
-                const int64_t jp = 2 * c + t / 8, z = t % 8;
-                if (jp >= P1) continue;
-                const int64_t q = (ip * P1 + jp) * E + z;
+                const int64_t bin = 2 * g + t / 8, z = t % 8;
+                if (bin >= NB) continue;
+                const int64_t q = bin * E + z;
                 long long dq;
                 if (m < K) {
                     dq = llround((lp[m * Q + q] - lip[m * Q + q]) * s);
@@ -418,7 +476,6 @@ int tsr_parts_mfma_prepare(tsr_ctx *ctx, tsr_parts *p, const double *lp, const d
                 }
                 kc[(size_t)((h * 2 + mt) * 16 + r)] = (int32_t)(v * 64 + m);
             }
-    p->pm_G1 = (int)G1;
     p->pm_NG = (int)NG;
     p->nkb = nkb;
     p->pm_n_inv = n_inv;
@@ -468,16 +525,14 @@ int tsr_launch_code_parts_mfma(tsr_ctx *ctx, const tsr_parts *p, const uint8_t *
     a.S = S;
     a.N1 = (int)N1;
     a.P0 = (int)p->P0;
+    a.P1 = (int)p->P1;
     a.CH = CH;
     a.nchunks = (int)((P + CH - 1) / CH);
     a.utt_end = d_utt_end;
     a.Wq = reinterpret_cast<const i32x4 *>(p->d_wq);
     a.Kc = p->d_kc;
-    a.G1 = p->pm_G1;
-    a.NG = p->pm_NG;
     a.K = (int)p->K;
     a.threshold = (unsigned)threshold;
-    a.fast = fast ? 1 : 0;
     a.o0_const = p->pm_o0_const;
     a.o0_slack = p->pm_o0_slack;
     a.n_inv = p->pm_n_inv;
@@ -487,14 +542,14 @@ int tsr_launch_code_parts_mfma(tsr_ctx *ctx, const tsr_parts *p, const uint8_t *
     a.list = d_list;
     int s = TSR_OK;
     switch (p->nkb) {
-    case 1: s = launch_nkb<1>(ctx, a, lds); break;
-    case 2: s = launch_nkb<2>(ctx, a, lds); break;
-    case 3: s = launch_nkb<3>(ctx, a, lds); break;
-    case 4: s = launch_nkb<4>(ctx, a, lds); break;
-    case 5: s = launch_nkb<5>(ctx, a, lds); break;
-    case 6: s = launch_nkb<6>(ctx, a, lds); break;
-    case 7: s = launch_nkb<7>(ctx, a, lds); break;
-    case 8: s = launch_nkb<8>(ctx, a, lds); break;
+    case 1: s = launch_nkb<1>(ctx, a, lds, fast != 0); break;
+    case 2: s = launch_nkb<2>(ctx, a, lds, fast != 0); break;
+    case 3: s = launch_nkb<3>(ctx, a, lds, fast != 0); break;
+    case 4: s = launch_nkb<4>(ctx, a, lds, fast != 0); break;
+    case 5: s = launch_nkb<5>(ctx, a, lds, fast != 0); break;
+    case 6: s = launch_nkb<6>(ctx, a, lds, fast != 0); break;
+    case 7: s = launch_nkb<7>(ctx, a, lds, fast != 0); break;
+    case 8: s = launch_nkb<8>(ctx, a, lds, fast != 0); break;
     default: return TSR_ERR_UNSUPPORTED;
     }
     TSR_TRY(s);

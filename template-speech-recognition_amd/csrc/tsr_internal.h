@@ -169,7 +169,7 @@ struct tsr_parts {
     int mode = 0;             // TSR_PARTS_AUTO / _VALU / _MFMA (tsr_parts_set_mode)
     bool mfma_ok = false;     // tables and geometry fit the MFMA coder
     char mfma_why[96] = {0};  // ... or why not
-    int nkb = 0, pm_G1 = 0, pm_NG = 0, pm_n_inv = 0;
+    int nkb = 0, pm_NG = 0, pm_n_inv = 0;
     float pm_o0_const = 0, pm_o0_slack = 0;
     void *d_wq = nullptr;     // int8 [mt 2][kb][limb 2][lane 64][16]
     int32_t *d_kc = nullptr;  // [half 2][mt 2][16]: (base sum << 6) | part

@@ -14,7 +14,7 @@ tot_loc = tot_re = 0
 for case in range(n_cases):
     while True:
         P0, P1 = int(rng.integers(1, 9)), int(rng.integers(1, 9))
-        if P0 * ((P1 + 1) // 2) <= 16:
+        if P0 * P1 <= 32:
             break
     K = int(rng.choice([1, 2, 5, 17, 31, 32, 33, 50, 63]))
     F = P1 + int(rng.integers(0, 30))
