@@ -99,8 +99,8 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
     const int row_bytes = (a.CH + a.P0 - 1) * a.Dp;
     uint8_t *rows = smem;
     int32_t *kcl = reinterpret_cast<int32_t *>(smem + row_bytes + kPad);  // [2][2][16]
-    int32_t *uendl = kcl + 64;                                             // [CH]
-    int32_t *chunkl = uendl + a.CH;
+    int32_t *livel = kcl + 64;                                             // [CH]: the frame takes patches
+    int32_t *chunkl = livel + a.CH;
 
     // weights: register-stationary for the life of the workgroup
     i32x4 W[2][NKB][2];
@@ -124,28 +124,11 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
     const i32x16 *const kc1 = reinterpret_cast<const i32x16 *>(kcl + (half * 2 + 1) * 16);
 
     const int64_t body = a.P * (int64_t)a.Dp;
-    const int nloc = a.CH * a.N1;  // live locations of a chunk, frame-major
+    const int nloc = a.CH * a.N1;  // live locations of a chunk, frame-major: location ll = frame * N1 + bin
     const int ntiles = (nloc + 31) / 32;
-    const float invN1 = 1.0f / (float)a.N1;
-    // frame (inside the chunk) and bin of this lane's location of a tile; false past the chunk's last location
-    auto locate = [&](int tile, int &fl, int &j) -> bool {
-        const int ll = tile * 32 + n;
-        fl = (int)((float)ll * invN1);
-        j = ll - fl * a.N1;
-        if (j < 0) {
-            --fl;
-            j += a.N1;
-        } else if (j >= a.N1) {
-            ++fl;
-            j -= a.N1;
-        }
-        return ll < nloc;
-    };
-    auto patch_addr = [&](int tile) -> const uint8_t * {
-        int fl, j;
-        const bool ok = locate(tile, fl, j);
-        return rows + (ok ? (fl * a.S + j) * 8 : 0);
-    };
+    const int dS = a.S - a.N1;                                     // position of location ll in frame fl: ll + fl * dS
+    const int adv_fl = (32 * kWaves) / a.N1, adv_j = (32 * kWaves) % a.N1;  // a wave's next tile is 32 * kWaves locations on
+    const bool wide = a.K > 56;  // part slots 56..62 in use (the keys of registers 12..15 of M-tile 1 count)
 
     for (;;) {
         __syncthreads();  // previous chunk fully consumed (and kcl visible the first time)
@@ -161,9 +144,11 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
                 if (off < row_bytes && g0 + off + 16 <= body) v = *reinterpret_cast<const i32x4 *>(a.X + g0 + off);
                 *reinterpret_cast<i32x4 *>(rows + off) = v << 6;  // bytes are 0 / 1: no carry between them
             }
-            if (tid < a.CH) uendl[tid] = (f0 + tid < a.P) ? a.utt_end[f0 + tid] : 0;
+            // a frame takes patches when the whole patch lies inside its utterance
+            if (tid < a.CH) livel[tid] = (f0 + tid < a.P && f0 + tid + a.P0 <= (int64_t)a.utt_end[f0 + tid]) ? 1 : 0;
         }
         __syncthreads();
+        const unsigned loc0 = (unsigned)(f0 * a.N1);  // (P * N1 < 2^31: checked at launch)
 
         int best = INT32_MIN, second = INT32_MIN;
         float vsum = 0.0f;
@@ -173,33 +158,34 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
             best = max(best, key);
             if (FAST) vsum += (float)(key >> 6);
         };
-        // everything behind the second M-tile of tile `tile`: margin test, list or id
-        auto finish = [&](int tile, int cnt_own) {
-            const int obest = __shfl_xor(best, 32), osecond = __shfl_xor(second, 32);
-            const unsigned count = (unsigned)__shfl(cnt_own, n + 32);  // the row of ones is slot 63: half 1, mt 1, r 15
-            const int mbest = max(best, obest);
-            const int msecond = max(min(best, obest), max(second, osecond));
+        // everything behind the second M-tile of the tile at locations ll (frame fl): margin test, list or id.
+        // v_permlane32_swap(x, x) = {x of lane & 31, x of lane | 32} in every lane.
+        auto finish = [&](int ll, int fl, int cnt_own) {
+            const auto bs = __builtin_amdgcn_permlane32_swap(best, best, false, false);
+            const auto ss = __builtin_amdgcn_permlane32_swap(second, second, false, false);
+            const auto cs = __builtin_amdgcn_permlane32_swap(cnt_own, cnt_own, false, false);
+            const unsigned count = cs[1];  // the row of ones is slot 63: half 1, M-tile 1, register 15
+            const int mbest = max((int)bs[0], (int)bs[1]);
+            const int msecond = max(min((int)bs[0], (int)bs[1]), max((int)ss[0], (int)ss[1]));
             const int vbest = mbest >> 6;
             const int window = (int)count + 2;
-            int fl, j;
-            const bool ok = locate(tile, fl, j);
-            const int64_t f = f0 + fl;
-            const bool live = ok && f < a.P && f + a.P0 <= (int64_t)uendl[ok ? fl : 0];
+            const bool live = ll < nloc && livel[fl] != 0;
             const bool coded = count >= a.threshold;
             bool flag = live && coded && (vbest - (msecond >> 6) <= window);
             bool full = false;
             if (FAST) {
-                const float vs = vsum + __shfl_xor(vsum, 32);
+                const auto vs2 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, vsum), __builtin_bit_cast(unsigned, vsum), false, false);
+                const float vs = __builtin_bit_cast(float, (unsigned)vs2[0]) + __builtin_bit_cast(float, (unsigned)vs2[1]);
                 // slot 0 = sum_k (S_k - 1) in units, pushed up by its error bound
                 const float o0 = vs - (float)a.n_inv * (float)kVInv - (float)count + a.o0_const +
                                  (float)a.K * (0.5f * (float)count + 1.0f) + a.o0_slack;
                 full = live && coded && o0 >= (float)(vbest - window);
                 flag = flag || full;
             }
-            const int64_t loc = f * a.N1 + j;
+            const unsigned loc = loc0 + (unsigned)ll;
             if (flag && half == 0) {  // rare: hand the location to the f64 re-evaluation
                 const int sl = atomicAdd(a.work + 1, 1);
-                a.list[(size_t)sl * 2] = (uint32_t)loc;
+                a.list[(size_t)sl * 2] = loc;
                 a.list[(size_t)sl * 2 + 1] = full ? 1u : 0u;
             }
             if (live && half == 0 && !flag) {
@@ -219,8 +205,21 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
         i32x16 accA[2], accB[2];
         i32x4 bf[NKB];
         int tile = wave;
+        int ll = tile * 32 + n, fl, j;  // this lane's location of the tile: frame fl, bin j of the chunk
+        {
+            fl = (int)((float)ll * (1.0f / (float)a.N1));
+            j = ll - fl * a.N1;
+            if (j < 0) {
+                --fl;
+                j += a.N1;
+            } else if (j >= a.N1) {
+                ++fl;
+                j -= a.N1;
+            }
+        }
+        auto patch_addr = [&]() -> const uint8_t * { return rows + (ll < nloc ? (ll + fl * dS) * 8 : 0); };
         if (tile < ntiles) {
-            const uint8_t *xa = patch_addr(tile);
+            const uint8_t *xa = patch_addr();
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
                 const i32x2 b0 = *reinterpret_cast<const i32x2 *>(xa + boff[kb][0]);
@@ -231,6 +230,7 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
             accB[0] = *kc1;
         }
         bool have_prev = false;
+        int ll_fin = 0, fl_fin = 0;  // the tile whose M-tile 1 is in accB
         for (; tile < ntiles; tile += kWaves) {
             // ---- step A
 #pragma unroll
@@ -239,12 +239,17 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
                 accA[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(W[0][kb][0], bf[kb], accA[0], 0, 0, 0);
                 if (have_prev) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e)
+                    for (int e = 0; e < 12; ++e)
                         if (e * SL / 16 == kb) slot(accB, e);
+                    if (wide) {
+#pragma unroll
+                        for (int e = 12; e < 16; ++e)
+                            if (e * SL / 16 == kb) slot(accB, e);
+                    }
                     if (kb == (SL < NKB ? SL : NKB - 1)) {
                         const int cnt_own = (accB[0][15] - kOnesKey) >> 6;
                         accB[0] = *kc1;
-                        finish(tile - kWaves, cnt_own);
+                        finish(ll_fin, fl_fin, cnt_own);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -253,13 +258,23 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
             best = INT32_MIN;
             second = INT32_MIN;
             vsum = 0.0f;
-            const bool more = tile + kWaves < ntiles;
-            const uint8_t *xn = patch_addr(more ? tile + kWaves : tile);
+            ll_fin = ll;
+            fl_fin = fl;
+            if (tile + kWaves < ntiles) {  // (the last tile fetches itself again)
+                ll += 32 * kWaves;
+                fl += adv_fl;
+                j += adv_j;
+                if (j >= a.N1) {
+                    j -= a.N1;
+                    ++fl;
+                }
+            }
+            const uint8_t *xn = patch_addr();
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
                 accB[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(W[1][kb][1], bf[kb], kb ? accB[1] : (i32x16){}, 0, 0, 0);
                 accB[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(W[1][kb][0], bf[kb], accB[0], 0, 0, 0);
-                {  // this K-block's operand of the wave's next tile (the last tile fetches itself again)
+                {  // this K-block's operand of the wave's next tile
                     const i32x2 b0 = *reinterpret_cast<const i32x2 *>(xn + boff[kb][0]);
                     const i32x2 b1 = *reinterpret_cast<const i32x2 *>(xn + boff[kb][1]);
                     bf[kb] = (i32x4){b0.x, b0.y, b1.x, b1.y};
@@ -275,7 +290,7 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
         if (have_prev) {  // the wave's last tile: nothing left to overlap
 #pragma unroll
             for (int e = 0; e < 16; ++e) slot(accB, e);
-            finish(tile - kWaves, (accB[0][15] - kOnesKey) >> 6);
+            finish(ll_fin, fl_fin, (accB[0][15] - kOnesKey) >> 6);
         }
     }
 }
@@ -287,7 +302,7 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
 // for bit, and the table is streamed once per kRcEnt entries instead of once per entry.  The
 // first maximum over the lanes is np.argmax's; for `full` entries slot 0 of code_parts_fast,
 // sum_k (S_k - 1) in ascending k (code_parts.pyx:289-293), decides between it and index 0.
-constexpr int kRcWaves = 4;
+constexpr int kRcWaves = 1;   // (one-wave blocks: the few thousand groups spread evenly over the SIMDs)
 constexpr int kRcEnt = 4;
 constexpr int kRcBins = 32;  // P0 * P1 <= 2 * (16 K-groups)
 
@@ -295,8 +310,8 @@ __global__ __launch_bounds__(64 * kRcWaves) void code_parts_recheck_kernel(
     const uint8_t *__restrict__ X, int Dp, int P0, int P1, int N1, const double *__restrict__ tab /*[Q][K][2]*/,
     int K, int fast, const uint32_t *__restrict__ list, const int *__restrict__ work, int32_t *__restrict__ argmax, int ids8)
 {
-    static_assert(kRcEnt == 4, "the bin word below holds 4 entries");
-    __shared__ __attribute__((aligned(4))) uint8_t xbits[kRcWaves][kRcBins][kRcEnt];  // one byte = the 8 edge bits of one bin of one entry's patch
+    static_assert(kRcEnt == 4 || kRcEnt == 8, "the bin words below hold 4 entries each");
+    __shared__ __attribute__((aligned(8))) uint32_t xbits[kRcWaves][kRcBins][kRcEnt / 4];  // one BYTE = the 8 edge bits of one bin of one entry's patch
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = work[1];
     const int nbins = P0 * P1;
@@ -304,13 +319,23 @@ __global__ __launch_bounds__(64 * kRcWaves) void code_parts_recheck_kernel(
     typedef double d2 __attribute__((ext_vector_type(2)));
     const d2 *t2 = reinterpret_cast<const d2 *>(tab) + kl;
     for (int e0 = (blockIdx.x * kRcWaves + wave) * kRcEnt; e0 < n; e0 += gridDim.x * kRcWaves * kRcEnt) {
-        for (int idx = lane; idx < nbins * kRcEnt; idx += 64) {  // E == 8: one bin = one aligned 8-byte word of 0/1 bytes
-            const int b = idx / kRcEnt, e = idx - b * kRcEnt;
+        {  // E == 8: one bin = one aligned 8-byte word of 0/1 bytes.  Lane = (entry, bin group): its location is read once,
+           // its bins are independent loads -- two round trips for the whole group
+            constexpr int kGroups = 64 / kRcEnt, kPer = kRcBins / kGroups;
+            const int e = lane % kRcEnt, g = lane / kRcEnt;
             const uint32_t loc = list[(size_t)min(e0 + e, n - 1) * 2];
             const int i0 = (int)(loc / (unsigned)N1), j0 = (int)(loc - (unsigned)i0 * (unsigned)N1);
-            const int i = b / P1, j = b - i * P1;
-            const uint64_t v = *reinterpret_cast<const uint64_t *>(X + (int64_t)(i0 + i) * Dp + (j0 + j) * 8);
-            xbits[wave][b][e] = (uint8_t)((v * 0x0102040810204080ull) >> 56);
+            uint64_t v[kPer];
+#pragma unroll
+            for (int q = 0; q < kPer; ++q) {
+                const int bq = min(g + kGroups * q, nbins - 1);
+                const int i = bq / P1, j = bq - i * P1;
+                v[q] = *reinterpret_cast<const uint64_t *>(X + (int64_t)(i0 + i) * Dp + (j0 + j) * 8);
+            }
+#pragma unroll
+            for (int q = 0; q < kPer; ++q)
+                if (g + kGroups * q < nbins)
+                    reinterpret_cast<uint8_t *>(&xbits[wave][g + kGroups * q][0])[e] = (uint8_t)((v[q] * 0x0102040810204080ull) >> 56);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -318,19 +343,49 @@ __global__ __launch_bounds__(64 * kRcWaves) void code_parts_recheck_kernel(
         double acc[kRcEnt];
 #pragma unroll
         for (int e = 0; e < kRcEnt; ++e) acc[e] = 0.0;
-        for (int b = 0; b < nbins; ++b) {
-            const uint32_t bw = *reinterpret_cast<const uint32_t *>(&xbits[wave][b][0]);  // the bin's bits of the 4 entries
-            d2 tv[8];
+        // the table values of bin b + 1 are in flight while bin b is summed (a bin's 8 loads per lane are one round
+        // trip to L2: unbuffered, the 25 bins of a 5 x 5 patch are 25 round trips in sequence -- all of the kernel's time)
+        d2 tv[2][8];
 #pragma unroll
-            for (int z = 0; z < 8; ++z) tv[z] = t2[(int64_t)(b * 8 + z) * K];
+        for (int z = 0; z < 8; ++z) tv[0][z] = t2[(int64_t)z * K];
+        // The edge bits are the same for every lane (a lane is a part): they go to scalar registers, a bit becomes a scalar
+        // mask 0 / ~0 (s_bfe_i32) and the select is two v_bfi_b32 on it -- three vector instructions per cell and entry
+        // with the add, and no select waits for another one's condition register (the compiler's own forms: two
+        // v_cndmask behind one vcc per select, every select waiting for the previous one's; or v_and + v_and_or).
+        // (NB: __builtin_bit_cast of an ext-vector ELEMENT reads element 0 with this compiler; hence the scalar copies.)
+        auto sum_bin = [&](int b, const d2 (&t)[8]) {
+            unsigned bw[kRcEnt / 4];  // the bin's bits of the entries
 #pragma unroll
-            for (int z = 0; z < 8; ++z)
+            for (int i = 0; i < kRcEnt / 4; ++i) bw[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)xbits[wave][b][i]);
+#pragma unroll
+            for (int z = 0; z < 8; ++z) {
+                const double tx = t[z].x, ty = t[z].y;
+                const int xl = __double2loint(tx), xh = __double2hiint(tx), yl = __double2loint(ty), yh = __double2hiint(ty);
 #pragma unroll
                 for (int e = 0; e < kRcEnt; ++e) {
-                    const unsigned byte = (bw >> (8 * e)) & 0xffu;
-                    acc[e] += ((byte >> z) & 1) ? tv[z].y : tv[z].x;
+                    const int m = (int)(bw[e >> 2] << (31 - (8 * (e & 3) + z))) >> 31;  // 0 or ~0
+                    int vl, vh;
+                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(vl) : "s"(m), "v"(yl), "v"(xl));
+                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(vh) : "s"(m), "v"(yh), "v"(xh));
+                    acc[e] += __hiloint2double(vh, vl);
                 }
+            }
+        };
+        int b = 0;
+        for (; b + 2 <= nbins; b += 2) {  // bins in pairs, nothing conditional inside (a load the compiler can sink into a branch is a round trip again)
+            const int b2 = min(b + 2, nbins - 1);
+#pragma unroll
+            for (int z = 0; z < 8; ++z) tv[1][z] = t2[(int64_t)((b + 1) * 8 + z) * K];
+            __builtin_amdgcn_sched_barrier(0);  // (the loads stay in front of the sums they overlap)
+            sum_bin(b, tv[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int z = 0; z < 8; ++z) tv[0][z] = t2[(int64_t)(b2 * 8 + z) * K];
+            __builtin_amdgcn_sched_barrier(0);
+            sum_bin(b + 1, tv[1]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (b < nbins) sum_bin(b, tv[0]);  // odd count: the last bin's values are the ones in flight
 #pragma unroll
         for (int e = 0; e < kRcEnt; ++e) {
             if (e0 + e >= n) break;  // uniform
@@ -553,7 +608,7 @@ int tsr_launch_code_parts_mfma(tsr_ctx *ctx, const tsr_parts *p, const uint8_t *
     default: return TSR_ERR_UNSUPPORTED;
     }
     TSR_TRY(s);
-    hipLaunchKernelGGL(code_parts_recheck_kernel, dim3((unsigned)(8 * std::max(ctx->cus, 1))), dim3(64 * kRcWaves), 0, ctx->stream,
+    hipLaunchKernelGGL(code_parts_recheck_kernel, dim3((unsigned)(32 * std::max(ctx->cus, 1) / kRcWaves)), dim3(64 * kRcWaves), 0, ctx->stream,
                        d_X, Dp, (int)p->P0, (int)p->P1, (int)N1, p->d_tab, (int)p->K, fast ? 1 : 0,
                        (const uint32_t *)d_list, (const int *)d_work, d_argmax, ids8);
     TSR_HIP(hipGetLastError());

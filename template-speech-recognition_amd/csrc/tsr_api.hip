@@ -568,6 +568,14 @@ static int corpus_alloc_bytes(tsr_ctx *ctx, tsr_corpus *cp)
     return TSR_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void zero_plane_tails_kernel(uint32_t *__restrict__ bits, int64_t plane_dwords, int64_t first, int count)
+{
+    uint32_t *p = bits + (int64_t)blockIdx.x * plane_dwords + first;
+    for (int i = threadIdx.x; i < count; i += 256) p[i] = 0;
+}
+}  // namespace
+
 int tsr_corpus_alloc_bits(tsr_ctx *ctx, tsr_corpus *cp)
 {
     tsr_bit_geometry(cp->D, &cp->bit_pw, &cp->bit_nph);
@@ -577,11 +585,13 @@ int tsr_corpus_alloc_bits(tsr_ctx *ctx, tsr_corpus *cp)
         tsr_set_error("tsr_corpus_part_features: cannot allocate %zu bytes of device memory", total);
         return TSR_ERR_HIP;
     }
-    for (int ph = 0; ph < cp->bit_nph; ++ph)  // the read-ahead rows behind the frames of every plane
-        if (hipMemsetAsync(cp->d_bits + (size_t)ph * plane + (size_t)cp->P * cp->bit_pw * 4, 0, (size_t)48 * cp->bit_pw * 4, ctx->stream) != hipSuccess) {
-            tsr_set_error("tsr_corpus_part_features: device memset failed");
-            return TSR_ERR_HIP;
-        }
+    // the read-ahead rows behind the frames of every plane: one launch for all planes
+    hipLaunchKernelGGL(zero_plane_tails_kernel, dim3((unsigned)cp->bit_nph), dim3(256), 0, ctx->stream, reinterpret_cast<uint32_t *>(cp->d_bits),
+                       (int64_t)(plane / 4), (int64_t)cp->P * cp->bit_pw, 48 * cp->bit_pw);
+    if (hipGetLastError() != hipSuccess) {
+        tsr_set_error("tsr_corpus_part_features: device launch failed");
+        return TSR_ERR_HIP;
+    }
     cp->bits_alloc = total;
     return TSR_OK;
 }
@@ -627,7 +637,10 @@ __global__ __launch_bounds__(256) void utt_tables_kernel(const int64_t *__restri
                                                          int32_t *__restrict__ end)
 {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= P) return;
+    if (p >= P) {
+        if (p < P + 256) end[p] = 0;  // the 256 ints behind utt_end that tiles read past P
+        return;
+    }
     int64_t lo = 0, hi = N;  // invariant: offs[lo] <= p < offs[hi]  (empty utterances share an offset: the last one wins, its end > p)
     while (hi - lo > 1) {
         const int64_t mid = (lo + hi) >> 1;
@@ -644,7 +657,7 @@ __global__ __launch_bounds__(256) void utt_tables_kernel(const int64_t *__restri
 // Allocate a corpus (resident feature rows zero-initialised only in the slack, utterance tables
 // made on the device, result arrays allocated) without any feature data.
 int tsr_corpus_create_empty(tsr_ctx *ctx, const int64_t *frame_offsets, int64_t N, int64_t D,
-                            tsr_corpus **out, bool alloc_bytes)
+                            tsr_corpus **out, bool alloc_bytes, const int64_t *d_off_ready)
 {
     TSR_REQUIRE(ctx && frame_offsets && out, "tsr_corpus_create: null pointer");
     *out = nullptr;
@@ -670,22 +683,25 @@ int tsr_corpus_create_empty(tsr_ctx *ctx, const int64_t *frame_offsets, int64_t 
     // per-frame utterance tables (first frame / end frame of the utterance holding p; 256 zero ints behind utt_end: tiles
     // read past P), made on the device from the N + 1 offsets; scores and ids are written before they are read
     auto grab = [&](void **q, size_t bytes) { return pool_malloc(cp->device, q, bytes) == hipSuccess ? TSR_OK : TSR_ERR_HIP; };
-    void *d_off = nullptr;
     if (s == TSR_OK) s = grab(reinterpret_cast<void **>(&cp->d_utt_beg), (size_t)std::max<int64_t>(P, 1) * 4);
     if (s == TSR_OK) s = grab(reinterpret_cast<void **>(&cp->d_utt_end), (size_t)(P + 256) * 4);
     if (s == TSR_OK) s = grab(reinterpret_cast<void **>(&cp->d_scores), (size_t)std::max<int64_t>(P, 1) * 4);
     if (s == TSR_OK) s = grab(reinterpret_cast<void **>(&cp->d_ids), (size_t)std::max<int64_t>(P, 1) * 4);
-    if (s == TSR_OK) s = tsr_scratch(ctx, SLOT_CNT, (size_t)(N + 1) * 8 + 64, &d_off);
-    if (s == TSR_OK && (hipMemcpyAsync(d_off, frame_offsets, (size_t)(N + 1) * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-                        hipMemsetAsync(cp->d_utt_end + P, 0, 256 * 4, ctx->stream) != hipSuccess))
-        s = TSR_ERR_HIP;
-    if (s == TSR_OK && P > 0) {
-        hipLaunchKernelGGL(utt_tables_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, (const int64_t *)d_off, N, P,
+    // (d_off_ready: the caller has the N + 1 offsets on the device already, enqueued on the stream, and synchronises itself)
+    const void *d_off = d_off_ready;
+    if (s == TSR_OK && !d_off_ready) {
+        void *q = nullptr;
+        s = tsr_scratch(ctx, SLOT_CNT, (size_t)(N + 1) * 8 + 64, &q);
+        d_off = q;
+        if (s == TSR_OK && hipMemcpyAsync(q, frame_offsets, (size_t)(N + 1) * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
+    }
+    if (s == TSR_OK) {  // (the grid covers the zeroed slack behind utt_end as well)
+        hipLaunchKernelGGL(utt_tables_kernel, dim3((unsigned)((P + 256 + 255) / 256)), dim3(256), 0, ctx->stream, (const int64_t *)d_off, N, P,
                            cp->d_utt_beg, cp->d_utt_end);
         if (hipGetLastError() != hipSuccess) s = TSR_ERR_HIP;
     }
     if (s == TSR_ERR_HIP) tsr_set_error("tsr_corpus_create: cannot allocate or fill the corpus tables");
-    if (s == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    if (s == TSR_OK && !d_off_ready && hipStreamSynchronize(ctx->stream) != hipSuccess) {
         tsr_set_error("tsr_corpus_create: upload failed");
         s = TSR_ERR_HIP;
     }
@@ -2113,29 +2129,40 @@ TSR_API int tsr_corpus_part_features(tsr_ctx *ctx, const tsr_parts *parts, const
     TSR_REQUIRE(want_bits || ctx->opt_part_layout != TSR_PART_LAYOUT_BITS,
                 "tsr_corpus_part_features: TSR_PART_LAYOUT_BITS, but the dilation cannot write bit rows for K=%lld, r0=%d", (long long)K, r0);
     TSR_TRY(tsr_corpus_need_bytes(ctx, edges));
+    // per-utterance tables: ONE upload (output offsets | first source frame | patch rows), everything per frame is made on
+    // the device; the host vectors outlive the copies (this call synchronises before it returns)
+    void *dGeo = nullptr;
+    const size_t geo_bytes = (size_t)(N + 1) * 8 + (size_t)std::max<int64_t>(N, 1) * 8;
+    TSR_TRY(tsr_scratch(ctx, SLOT_IN, geo_bytes, &dGeo));
+    std::vector<int64_t> geo(geo_bytes / 8, 0);
+    memcpy(geo.data(), ooff.data(), (size_t)(N + 1) * 8);
+    memcpy(reinterpret_cast<char *>(geo.data()) + (size_t)(N + 1) * 8, ubeg.data(), (size_t)N * 4);
+    memcpy(reinterpret_cast<char *>(geo.data()) + (size_t)(N + 1) * 8 + (size_t)N * 4, un0.data(), (size_t)N * 4);
+    TSR_HIP(hipMemcpyAsync(dGeo, geo.data(), geo_bytes, hipMemcpyHostToDevice, ctx->stream));
+    int64_t *d_ooff = (int64_t *)dGeo;
+    int32_t *d_beg = (int32_t *)(d_ooff + N + 1), *d_n0 = d_beg + N;
     tsr_corpus *cp = nullptr;
-    TSR_TRY(tsr_corpus_create_empty(ctx, ooff.data(), N, O1 * K, &cp, !want_bits));
+    {
+        const int sc = tsr_corpus_create_empty(ctx, ooff.data(), N, O1 * K, &cp, !want_bits, d_ooff);
+        if (sc != TSR_OK) {
+            (void)hipStreamSynchronize(ctx->stream);  // (the upload reads host vectors of this frame)
+            return sc;
+        }
+    }
     if (want_bits) {
         const int sb = tsr_corpus_alloc_bits(ctx, cp);
         if (sb != TSR_OK) {
+            (void)hipStreamSynchronize(ctx->stream);
             tsr_corpus_destroy(cp);
             return sb;
         }
     }
-    void *dA = nullptr, *dRow = nullptr, *dG = nullptr, *dGm = nullptr, *dGeo = nullptr;
+    void *dA = nullptr, *dRow = nullptr, *dG = nullptr, *dGm = nullptr;
     int s = tsr_scratch(ctx, SLOT_AUX, (size_t)std::max<int64_t>(edges->P * N1, 1) * 4, &dA);
     if (s == TSR_OK) s = tsr_scratch(ctx, SLOT_W, (size_t)std::max<int64_t>(P_out, 1) * 12, &dRow);
-    if (s == TSR_OK) s = tsr_scratch(ctx, SLOT_IN, (size_t)(N + 1) * 8 + (size_t)std::max<int64_t>(N, 1) * 8, &dGeo);
     int32_t *d_src_row = (int32_t *)dRow, *d_src_lo = d_src_row + P_out, *d_src_hi = d_src_lo + P_out;
-    if (s == TSR_OK && P_out > 0) {  // per-utterance tables up, per-frame tables made on the device
-        int64_t *d_ooff = (int64_t *)dGeo;
-        int32_t *d_beg = (int32_t *)(d_ooff + N + 1), *d_n0 = d_beg + N;
-        if (hipMemcpyAsync(d_ooff, ooff.data(), (size_t)(N + 1) * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(d_beg, ubeg.data(), (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(d_n0, un0.data(), (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-            s = TSR_ERR_HIP;
-        if (s == TSR_OK) s = tsr_launch_out_geometry(ctx, d_ooff, d_beg, d_n0, N, g0, P_out, d_src_row, d_src_lo, d_src_hi);
-    }
+    if (s == TSR_OK && P_out > 0)
+        s = tsr_launch_out_geometry(ctx, d_ooff, d_beg, d_n0, N, g0, P_out, d_src_row, d_src_lo, d_src_hi);
     std::vector<uint64_t> gmasks;  // graph rows as part masks (K <= 64), behind the K*K bytes
     if (s == TSR_OK && graph) {
         gmasks.assign((size_t)K, 0);
@@ -2193,6 +2220,7 @@ TSR_API int tsr_corpus_part_features(tsr_ctx *ctx, const tsr_parts *parts, const
     }
     if (s != TSR_OK) {
         if (s == TSR_ERR_HIP) tsr_set_error("tsr_corpus_part_features: device copy/launch failed");
+        (void)hipStreamSynchronize(ctx->stream);  // (nothing of this frame may still be read by a copy)
         tsr_corpus_destroy(cp);
         return s;
     }

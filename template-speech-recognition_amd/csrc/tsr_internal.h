@@ -70,7 +70,7 @@ int tsr_scratch(tsr_ctx *ctx, int slot, size_t bytes, void **out);
 // buffer (a D2H straight into fresh pageable memory re-pins the pages on every call: 0.4 vs 5 ms for 3 MB).
 int tsr_download(tsr_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 int tsr_corpus_create_empty(tsr_ctx *ctx, const int64_t *frame_offsets, int64_t N, int64_t D,
-                            struct tsr_corpus **out, bool alloc_bytes = true);
+                            struct tsr_corpus **out, bool alloc_bytes = true, const int64_t *d_off_ready = nullptr);
 
 // ---- bank ---------------------------------------------------------------------
 // Exact path: templates in groups of TSR_MG; group g holds, for every (tau, d),
