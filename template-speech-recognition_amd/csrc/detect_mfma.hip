@@ -631,14 +631,17 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
         return TSR_ERR_UNSUPPORTED;
     }
     // segments: one workgroup per (segment, column group); one wave of workgroups per launch
-    int nseg = std::max(1, ctx->cus / fb->G);
+    // K-phases of the two-limb kernel share ONE launch: a block is (phase, segment, column group), the segments six
+    // (n_phase) times as long -- five launch ramps fewer, and a tile stream long enough to run in its steady state
+    const bool phase_grid = fb->n_phase > 1 && NL == 2 && !bf;
+    int nseg = std::max(1, ctx->cus / (fb->G * (phase_grid ? fb->n_phase : 1)));
     const int64_t min_rows = 64;  // do not cut the stream finer than two tiles per segment
     nseg = (int)std::max<int64_t>(1, std::min<int64_t>(nseg, (P + min_rows - 1) / min_rows));
     // Several column groups: the G workgroups of a segment go to one XCD (so that its L2 serves the
     // re-reads), in two rounds of workgroups per CU slot: spx = floor(2 * CUs-per-XCD / G) segments per XCD
     // keep >= 98 % of the slots busy for G <= 9 where one round would leave up to G - 1 of 32 idle.
     int spx = 0;
-    if (fb->G > 1 && fb->G <= 2 * (ctx->cus / 8)) {
+    if (fb->G > 1 && fb->G <= 2 * (ctx->cus / 8) && !phase_grid) {
         const int want = (2 * (ctx->cus / 8)) / fb->G;
         if (ctx->opt_xcd_map && want >= 1 && (int64_t)8 * want * min_rows * 4 <= P) {
             spx = want;
@@ -650,16 +653,22 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
     const bool fragments = fb->n_phase > 1 || fb->G > 1;
     void *raw_frag = nullptr;
     if (fragments) TSR_TRY(tsr_scratch(ctx, 0, (size_t)fb->n_frag * P * sizeof(float), &raw_frag));
-    const int grid = nseg * fb->G;
+    const int grid = nseg * fb->G * (phase_grid ? fb->n_phase : 1);
     const bool flat = (SB == Dp) && fb->n_phase == 1 && !bits;
     unsigned long long *d_dbg = nullptr;
 #ifdef TSR_STAMP
     TSR_HIP(hipMalloc(reinterpret_cast<void **>(&d_dbg), (size_t)grid * kWaves * 6 * 8));
     TSR_HIP(hipMemsetAsync(d_dbg, 0, (size_t)grid * kWaves * 6 * 8, ctx->stream));
 #endif
-    for (int ph = 0; ph < fb->n_phase; ++ph) {
+    for (int ph = 0; ph < (phase_grid ? 1 : fb->n_phase); ++ph) {
         FastArgs a;
         memset(&a, 0, sizeof a);
+        if (phase_grid) {
+            a.n_phase = fb->n_phase;
+            a.x_phase_bytes = bits ? (long long)cp->bit_rows * cp->bit_pw * 4 : (long long)k_span;
+            a.wl_phase = (long long)fb->wl_phase;
+            a.slot_phase = fb->G * kMaxSlots;
+        }
         a.X = bf ? reinterpret_cast<const uint8_t *>(cp->d_feats_bf16) : cp->d_feats + (size_t)ph * k_span;  // this phase's feature range of every row
         a.Dp = Dp;
         a.SB = SB;
@@ -695,11 +704,12 @@ int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int
             a.ids = d_ids;
             a.all = d_all;
         }
+        const int ph_last = phase_grid ? fb->n_phase - 1 : ph;  // the furthest feature range this launch reads
         if (bits) {  // whole bit rows of the tiles' 32 frames: the last tile starts at a frame of the corpus
-            TSR_REQUIRE(P + 31 <= cp->bit_rows && (size_t)(ph + 1) * (size_t)cp->bit_rows * cp->bit_pw * 4 <= cp->bits_alloc,
+            TSR_REQUIRE(P + 31 <= cp->bit_rows && (size_t)(ph_last + 1) * (size_t)cp->bit_rows * cp->bit_pw * 4 <= cp->bits_alloc,
                         "TSR_FAST: frame staging would read past the %zu-byte bit form", cp->bits_alloc);
         } else {  // the staging's read-ahead stays inside the array it reads (tsr_internal.h: tsr_staging_read_end)
-            const size_t end = tsr_staging_read_end(P, Dp, SB, a.src_slots, tile_bytes, flat, bf ? 0 : (size_t)ph * k_span);
+            const size_t end = tsr_staging_read_end(P, Dp, SB, a.src_slots, tile_bytes, flat, bf ? 0 : (size_t)ph_last * k_span);
             const size_t have = bf ? cp->bf16_alloc : cp->feats_alloc;
             TSR_REQUIRE(end <= have, "TSR_FAST: frame staging would read %zu bytes of a %zu-byte %s array (P=%lld, row %d, tile %d)",
                         end, have, bf ? "bf16" : "feature", (long long)P, Dp, tile_bytes);
