@@ -38,15 +38,37 @@ __global__ __launch_bounds__(256) void frag_epilogue_kernel(
     const int64_t end = utt_end[p];
     float best = 0.0f;
     int besti = 0;
-    for (int m = 0; m < M; ++m) {
-        float r = 0.0f;
-        for (int f = frag_ptr[m]; f < frag_ptr[m + 1]; ++f) r += raw_frag[(int64_t)frag_idx[f] * P + p];
-        if (p + L[m] > end) r = 0.0f;
-        const float v = r + cf[m];
-        if (all) all[(int64_t)m * P + p] = v;
-        if (m == 0 || v > best) {
-            best = v;
-            besti = m;
+    // four templates at a time: their fragment loads of one round are independent of each other (a lane has four loads
+    // in flight instead of one); every template's own sum keeps the order of its fragments
+    for (int m0 = 0; m0 < M; m0 += 4) {
+        float r[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        int f0[4], nf[4], nmax = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = min(m0 + i, M - 1);
+            f0[i] = frag_ptr[m];
+            nf[i] = m0 + i < M ? frag_ptr[m + 1] - f0[i] : 0;
+            nmax = max(nmax, nf[i]);
+        }
+        for (int f = 0; f < nmax; ++f) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = f < nf[i] ? raw_frag[(int64_t)frag_idx[f0[i] + f] * P + p] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (f < nf[i]) r[i] += v[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + i;
+            if (m >= M) break;
+            if (p + L[m] > end) r[i] = 0.0f;
+            const float v = r[i] + cf[m];
+            if (all) all[(int64_t)m * P + p] = v;
+            if (m == 0 || v > best) {
+                best = v;
+                besti = m;
+            }
         }
     }
     if (scores) scores[p] = best;

@@ -490,32 +490,73 @@ __device__ __forceinline__ unsigned long long wave_shift1(unsigned long long v, 
     return ((unsigned long long)(unsigned)h2 << 32) | (unsigned)l2;
 }
 
-template <bool IDS8>
+// R0: the row radius as a compile-time constant (0..3), or -1 for any radius.  With it a wave whose frames' windows are
+// whole and consecutive (no utterance edge inside them, grid step 1) reads every source row ONCE, all loads in flight
+// together, and slides the window over masks in registers (static indices); other waves read per frame.
+template <bool IDS8, int R0>
 __global__ __launch_bounds__(256) void spread_lane_bits_kernel(
     const void *__restrict__ Aany, int N1, int r0, int r1, int K, int g1, int O1, int64_t P_out,
     const int32_t *__restrict__ out_src_row, const int32_t *__restrict__ out_src_lo, const int32_t *__restrict__ out_src_hi,
     const uint64_t *__restrict__ graph_masks /*[K] or null*/, uint32_t *__restrict__ o32, int bit_pw, int bit_nph, int64_t bit_rows)
 {
-    __shared__ unsigned long long strip[4][kLaneFrames][64];  // per wave: the frames' column masks
+    __shared__ unsigned long long buf[4][kLaneFrames][64];  // per wave: the frames' column masks
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = bit_nph * bit_pw;                      // dwords of a frame's bit form
     const int64_t q0 = ((int64_t)blockIdx.x * 4 + wave) * kLaneFrames;
     if (q0 >= P_out) return;
     const int nf = (int)min((int64_t)kLaneFrames, P_out - q0);
-    const int nw = bit_nph * bit_pw;                      // dwords of a frame's bit form
     const int j = lane * g1;                              // source bin of this lane's output column
     const int lo1 = max(j - r1, 0), hi1 = min(j + r1 + 1, N1);
-    // ---- A. per frame: rows OR-ed per bin, box over the bins, closure -> strip[f][column] ------------------------
-    for (int f = 0; f < nf; ++f) {
-        const int64_t q = q0 + f;
-        const int i = out_src_row[q];
-        const int lo = max(i - r0, out_src_lo[q]), hi = max(min(i + r0 + 1, out_src_hi[q]), lo);  // (wave-uniform)
-        unsigned long long m = 0;
-        if (lane < N1)
-            for (int x0 = lo; x0 < hi; ++x0) {
-                const int64_t at = (int64_t)x0 * N1 + lane;
-                const int p = IDS8 ? (int)static_cast<const uint8_t *>(Aany)[at] : static_cast<const int32_t *>(Aany)[at];
-                m |= p > 0 ? 1ull << (p - 1) : 0ull;
+    // one-hot mask of a part id (0 = none) as two dwords
+    auto one_hot = [](int p) -> unsigned long long {
+        const int b = p - 1;
+        const unsigned lo = (unsigned)b < 32u ? 1u << (b & 31) : 0u, hi = (unsigned)(b - 32) < 32u ? 1u << (b & 31) : 0u;
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    auto part_at = [&](int64_t at) -> int {
+        return IDS8 ? (int)static_cast<const uint8_t *>(Aany)[at] : static_cast<const int32_t *>(Aany)[at];
+    };
+    // ---- A. per frame: the rows of its window OR-ed per bin -------------------------------------------------------
+    unsigned long long rowor[kLaneFrames];
+    bool sliding = false;
+    if (R0 >= 0) {  // (wave-uniform) whole consecutive windows inside one utterance?
+        const int i0 = out_src_row[q0], i7 = out_src_row[q0 + nf - 1];
+        sliding = nf == kLaneFrames && i7 == i0 + kLaneFrames - 1 && out_src_lo[q0] == out_src_lo[q0 + nf - 1] &&
+                  i0 - R0 >= out_src_lo[q0] && i7 + R0 + 1 <= out_src_hi[q0 + nf - 1];
+        if (sliding) {
+            constexpr int NR = kLaneFrames + 2 * (R0 >= 0 ? R0 : 0);
+            int pk[NR];
+#pragma unroll
+            for (int k = 0; k < NR; ++k) pk[k] = lane < N1 ? part_at((int64_t)(i0 - R0 + k) * N1 + lane) : 0;
+            unsigned long long rm[NR];
+#pragma unroll
+            for (int k = 0; k < NR; ++k) rm[k] = one_hot(pk[k]);
+#pragma unroll
+            for (int f = 0; f < kLaneFrames; ++f) {
+                unsigned long long m = rm[f];
+#pragma unroll
+                for (int d = 1; d <= 2 * (R0 >= 0 ? R0 : 0); ++d) m |= rm[f + d];
+                rowor[f] = m;
             }
+        }
+    }
+    if (!sliding) {
+#pragma unroll
+        for (int f = 0; f < kLaneFrames; ++f) {
+            unsigned long long m = 0;
+            if (f < nf && lane < N1) {
+                const int64_t q = q0 + f;
+                const int i = out_src_row[q];
+                const int lo = max(i - r0, out_src_lo[q]), hi = max(min(i + r0 + 1, out_src_hi[q]), lo);  // (wave-uniform)
+                for (int x0 = lo; x0 < hi; ++x0) m |= one_hot(part_at((int64_t)x0 * N1 + lane));
+            }
+            rowor[f] = m;
+        }
+    }
+    // ---- B. box over the bins, closure -> the frame's column masks ---------------------------------------------------
+#pragma unroll
+    for (int f = 0; f < kLaneFrames; ++f) {
+        const unsigned long long m = rowor[f];
         unsigned long long mc = m;                        // this output column's box over the source bins
         if (g1 == 1) {                                    // neighbours by wavefront shifts (bins >= N1 hold no parts)
             unsigned long long up = m, dn = m;
@@ -535,31 +576,46 @@ __global__ __launch_bounds__(256) void spread_lane_bits_kernel(
         if (graph_masks)
             for (int a = 0; a < K; ++a)
                 if ((mc >> a) & 1) mc |= graph_masks[a];
-        strip[wave][f][lane] = mc;
+        buf[wave][f][lane] = mc;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- B. the bit streams (bit oj K + k), one output DWORD per lane and round, the same dword of every frame:
-    //      bits [32 w, 32 w + 32) come from the columns first .. first + cmax - 1 at fixed shifts -----------------------
+    // ---- C. the bit streams (bit oj K + k), one output DWORD per lane: bits [32 w, 32 w + 32) come from the columns
+    //      first .. first + cmax - 1 at fixed shifts (all of them 32-bit: v_alignbit brings down what comes from the upper
+    //      half of a mask).  Whole rounds of 64 dwords run frame by frame with everything but the frame hoisted; the
+    //      dwords left over (nw mod 64: 2 of 66 at config 3) of ALL the wave's frames share one last round ----------------
     const int cmax = (31 + K) / K + 1;                    // output columns that can overlap one dword
-    for (int w0 = 0; w0 < nw; w0 += 64) {
+    auto dword_of = [&](int f, int w, int first) -> unsigned {
+        unsigned acc = 0;
+        for (int c = 0; c < cmax; ++c) {
+            const int oj = first + c;
+            const int pos = oj * K - 32 * w;           // bit of the dword where this column's mask starts
+            if (oj < O1 && pos < 32) {
+                const unsigned long long v = buf[wave][f][oj];
+                const unsigned vl = (unsigned)v, vh = (unsigned)(v >> 32);
+                const int sdown = -pos;                 // (pos < 0) the mask starts sdown bits below the dword
+                const unsigned down = __builtin_amdgcn_alignbit(sdown >= 32 ? 0u : vh, sdown >= 32 ? vh : vl, (unsigned)sdown & 31u);
+                acc |= pos >= 0 ? vl << (pos & 31) : down;
+            }
+        }
+        return acc;
+    };
+    const int full = nw & ~63, rem = nw - full;
+    const bool packed = rem > 0 && rem * kLaneFrames <= 64;   // the leftover dwords of every frame fit one round
+    for (int w0 = 0; w0 < (packed ? full : nw); w0 += 64) {
         const int w = w0 + lane;
         if (w >= nw) continue;
         const int first = (32 * w) / K;
         const int ph = w / bit_pw, jj = w - ph * bit_pw;
         uint32_t *dst = o32 + ((int64_t)ph * bit_rows + q0) * bit_pw + jj;
-        for (int f = 0; f < nf; ++f) {
-            unsigned acc = 0;
-            for (int c = 0; c < cmax; ++c) {
-                const int oj = first + c;
-                const int pos = oj * K - 32 * w;           // bit of the dword where this column's mask starts
-                if (oj < O1 && pos < 32) {
-                    const unsigned long long v = strip[wave][f][oj];
-                    acc |= pos >= 0 ? (unsigned)(v << pos) : (unsigned)(v >> -pos);
-                }
-            }
-            dst[(int64_t)f * bit_pw] = acc;
+        for (int f = 0; f < nf; ++f) dst[(int64_t)f * bit_pw] = dword_of(f, w, first);
+    }
+    if (packed) {
+        const int f = lane / rem, w = full + lane - f * rem;
+        if (f < nf) {
+            const int ph = w / bit_pw, jj = w - ph * bit_pw;
+            o32[((int64_t)ph * bit_rows + q0 + f) * bit_pw + jj] = dword_of(f, w, (32 * w) / K);
         }
     }
 }
@@ -590,7 +646,6 @@ int tsr_launch_spread_stream(tsr_ctx *ctx, const int32_t *d_A, int64_t N1, int r
                              int64_t bit_rows, int ids8)
 {
     const int Bp = bit_pw * bit_nph;  // dwords of a frame's bit form
-    (void)g0;
     const int64_t n = P_out * O1;
     if (n <= 0) return TSR_OK;
     if (d_out_bits && !tsr_spread_packs_bits(N1, r0, K, Dp_out, Bp)) {
@@ -600,14 +655,29 @@ int tsr_launch_spread_stream(tsr_ctx *ctx, const int32_t *d_A, int64_t N1, int r
     if (d_out_bits && N1 <= 64 && O1 <= 64 && K <= 64 && !g_spread_old) {  // the register kernel writes the bit form directly
         const int64_t fpb = 4 * kLaneFrames;
         const dim3 grid((unsigned)((P_out + fpb - 1) / fpb));
-        if (ids8)
-            hipLaunchKernelGGL(spread_lane_bits_kernel<true>, grid, dim3(256), 0, ctx->stream, (const void *)d_A, (int)N1, r0, r1, (int)K, g1,
-                               (int)O1, P_out, d_src_row, d_src_lo, d_src_hi, d_graph ? d_graph_masks : nullptr,
-                               reinterpret_cast<uint32_t *>(d_out_bits), bit_pw, bit_nph, bit_rows);
-        else
-            hipLaunchKernelGGL(spread_lane_bits_kernel<false>, grid, dim3(256), 0, ctx->stream, (const void *)d_A, (int)N1, r0, r1, (int)K, g1,
-                               (int)O1, P_out, d_src_row, d_src_lo, d_src_hi, d_graph ? d_graph_masks : nullptr,
-                               reinterpret_cast<uint32_t *>(d_out_bits), bit_pw, bit_nph, bit_rows);
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, grid, dim3(256), 0, ctx->stream, (const void *)d_A, (int)N1, r0, r1, (int)K, g1, (int)O1, P_out, d_src_row,
+                               d_src_lo, d_src_hi, d_graph ? d_graph_masks : nullptr, reinterpret_cast<uint32_t *>(d_out_bits), bit_pw, bit_nph,
+                               bit_rows);
+        };
+        const int r0c = (g0 == 1 && r0 <= 3) ? r0 : -1;  // row radius as a constant: windows slide over masks in registers
+        if (ids8) {
+            switch (r0c) {
+            case 0: go(spread_lane_bits_kernel<true, 0>); break;
+            case 1: go(spread_lane_bits_kernel<true, 1>); break;
+            case 2: go(spread_lane_bits_kernel<true, 2>); break;
+            case 3: go(spread_lane_bits_kernel<true, 3>); break;
+            default: go(spread_lane_bits_kernel<true, -1>); break;
+            }
+        } else {
+            switch (r0c) {
+            case 0: go(spread_lane_bits_kernel<false, 0>); break;
+            case 1: go(spread_lane_bits_kernel<false, 1>); break;
+            case 2: go(spread_lane_bits_kernel<false, 2>); break;
+            case 3: go(spread_lane_bits_kernel<false, 3>); break;
+            default: go(spread_lane_bits_kernel<false, -1>); break;
+            }
+        }
         TSR_HIP(hipGetLastError());
         return TSR_OK;
     }
