@@ -453,6 +453,40 @@ __global__ __launch_bounds__(256) void out_geometry_kernel(const int64_t *__rest
     src_lo[q] = beg[lo];
     src_hi[q] = beg[lo] + n0[lo];
 }
+
+// Everything the part chain needs per frame before its first real kernel, in ONE launch: the source-row geometry of every
+// output frame (as out_geometry_kernel), the utterance tables of the new corpus (as tsr_api.hip's utt_tables_kernel: both
+// come out of the same search over the output offsets), the zeroed read-ahead rows behind the bit planes and the zeroed
+// work counters of the coder.
+__global__ __launch_bounds__(256) void part_chain_setup_kernel(const int64_t *__restrict__ ooff, const int32_t *__restrict__ beg,
+                                                               const int32_t *__restrict__ n0, int64_t N, int g0, int64_t P_out,
+                                                               int32_t *__restrict__ src_row, int32_t *__restrict__ src_lo,
+                                                               int32_t *__restrict__ src_hi, int32_t *__restrict__ utt_beg,
+                                                               int32_t *__restrict__ utt_end, uint32_t *__restrict__ bits,
+                                                               int64_t plane_dwords, int64_t tail_first, int tail_count, int n_planes,
+                                                               int *__restrict__ work)
+{
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q < 2 && work) work[q] = 0;
+    if (bits && q < (int64_t)n_planes * tail_count) bits[(q / tail_count) * plane_dwords + tail_first + q % tail_count] = 0;
+    if (q >= P_out) {
+        if (q < P_out + 256) utt_end[q] = 0;  // the 256 ints behind utt_end that tiles read past the last frame
+        return;
+    }
+    int64_t lo = 0, hi = N;  // last n with ooff[n] <= q
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (ooff[mid] <= q)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    src_row[q] = beg[lo] + (int32_t)(q - ooff[lo]) * g0;
+    src_lo[q] = beg[lo];
+    src_hi[q] = beg[lo] + n0[lo];
+    utt_beg[q] = (int32_t)ooff[lo];
+    utt_end[q] = (int32_t)ooff[lo + 1];
+}
 }  // namespace
 
 int tsr_launch_out_geometry(tsr_ctx *ctx, const int64_t *d_ooff, const int32_t *d_beg, const int32_t *d_n0, int64_t N,
@@ -461,6 +495,19 @@ int tsr_launch_out_geometry(tsr_ctx *ctx, const int64_t *d_ooff, const int32_t *
     if (P_out <= 0) return TSR_OK;
     hipLaunchKernelGGL(out_geometry_kernel, dim3((unsigned)((P_out + 255) / 256)), dim3(256), 0, ctx->stream, d_ooff, d_beg,
                        d_n0, N, g0, P_out, d_src_row, d_src_lo, d_src_hi);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}
+
+int tsr_launch_part_chain_setup(tsr_ctx *ctx, const int64_t *d_ooff, const int32_t *d_beg, const int32_t *d_n0, int64_t N, int g0,
+                                int64_t P_out, int32_t *d_src_row, int32_t *d_src_lo, int32_t *d_src_hi, int32_t *d_utt_beg,
+                                int32_t *d_utt_end, uint32_t *d_bits, int64_t plane_dwords, int64_t tail_first, int tail_count,
+                                int n_planes, int *d_work)
+{
+    const int64_t n = std::max<int64_t>(P_out + 256, (int64_t)n_planes * tail_count);
+    hipLaunchKernelGGL(part_chain_setup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_ooff, d_beg, d_n0, N, g0,
+                       P_out, d_src_row, d_src_lo, d_src_hi, d_utt_beg, d_utt_end, d_bits, plane_dwords, tail_first, tail_count, n_planes,
+                       d_work);
     TSR_HIP(hipGetLastError());
     return TSR_OK;
 }

@@ -572,7 +572,7 @@ int tsr_launch_code_parts_mfma(tsr_ctx *ctx, const tsr_parts *p, const uint8_t *
         }
     }
     if (!CH) return TSR_ERR_UNSUPPORTED;
-    TSR_HIP(hipMemsetAsync(d_work, 0, 2 * sizeof(int), ctx->stream));
+    // (d_work[0..1] = 0: the caller's setup kernel)
     PmArgs a;
     a.X = d_X;
     a.P = P;

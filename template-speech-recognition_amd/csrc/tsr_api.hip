@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256) void zero_plane_tails_kernel(uint32_t *__restr
 }
 }  // namespace
 
-int tsr_corpus_alloc_bits(tsr_ctx *ctx, tsr_corpus *cp)
+int tsr_corpus_alloc_bits(tsr_ctx *ctx, tsr_corpus *cp, bool zero_tails)
 {
     tsr_bit_geometry(cp->D, &cp->bit_pw, &cp->bit_nph);
     cp->bit_rows = cp->P + 48;  // (tiles of the bank pass read whole 32-frame tiles: the last one starts at a frame of the corpus)
@@ -585,8 +585,8 @@ int tsr_corpus_alloc_bits(tsr_ctx *ctx, tsr_corpus *cp)
         tsr_set_error("tsr_corpus_part_features: cannot allocate %zu bytes of device memory", total);
         return TSR_ERR_HIP;
     }
-    // the read-ahead rows behind the frames of every plane: one launch for all planes
-    hipLaunchKernelGGL(zero_plane_tails_kernel, dim3((unsigned)cp->bit_nph), dim3(256), 0, ctx->stream, reinterpret_cast<uint32_t *>(cp->d_bits),
+    // the read-ahead rows behind the frames of every plane: one launch for all planes (or the caller's setup kernel)
+    if (zero_tails) hipLaunchKernelGGL(zero_plane_tails_kernel, dim3((unsigned)cp->bit_nph), dim3(256), 0, ctx->stream, reinterpret_cast<uint32_t *>(cp->d_bits),
                        (int64_t)(plane / 4), (int64_t)cp->P * cp->bit_pw, 48 * cp->bit_pw);
     if (hipGetLastError() != hipSuccess) {
         tsr_set_error("tsr_corpus_part_features: device launch failed");
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256) void utt_tables_kernel(const int64_t *__restri
 // Allocate a corpus (resident feature rows zero-initialised only in the slack, utterance tables
 // made on the device, result arrays allocated) without any feature data.
 int tsr_corpus_create_empty(tsr_ctx *ctx, const int64_t *frame_offsets, int64_t N, int64_t D,
-                            tsr_corpus **out, bool alloc_bytes, const int64_t *d_off_ready)
+                            tsr_corpus **out, bool alloc_bytes, const int64_t *d_off_ready, bool tables)
 {
     TSR_REQUIRE(ctx && frame_offsets && out, "tsr_corpus_create: null pointer");
     *out = nullptr;
@@ -689,13 +689,13 @@ int tsr_corpus_create_empty(tsr_ctx *ctx, const int64_t *frame_offsets, int64_t 
     if (s == TSR_OK) s = grab(reinterpret_cast<void **>(&cp->d_ids), (size_t)std::max<int64_t>(P, 1) * 4);
     // (d_off_ready: the caller has the N + 1 offsets on the device already, enqueued on the stream, and synchronises itself)
     const void *d_off = d_off_ready;
-    if (s == TSR_OK && !d_off_ready) {
+    if (s == TSR_OK && !d_off_ready && tables) {
         void *q = nullptr;
         s = tsr_scratch(ctx, SLOT_CNT, (size_t)(N + 1) * 8 + 64, &q);
         d_off = q;
         if (s == TSR_OK && hipMemcpyAsync(q, frame_offsets, (size_t)(N + 1) * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) s = TSR_ERR_HIP;
     }
-    if (s == TSR_OK) {  // (the grid covers the zeroed slack behind utt_end as well)
+    if (s == TSR_OK && tables) {  // (the grid covers the zeroed slack behind utt_end as well)
         hipLaunchKernelGGL(utt_tables_kernel, dim3((unsigned)((P + 256 + 255) / 256)), dim3(256), 0, ctx->stream, (const int64_t *)d_off, N, P,
                            cp->d_utt_beg, cp->d_utt_end);
         if (hipGetLastError() != hipSuccess) s = TSR_ERR_HIP;
@@ -2143,14 +2143,14 @@ TSR_API int tsr_corpus_part_features(tsr_ctx *ctx, const tsr_parts *parts, const
     int32_t *d_beg = (int32_t *)(d_ooff + N + 1), *d_n0 = d_beg + N;
     tsr_corpus *cp = nullptr;
     {
-        const int sc = tsr_corpus_create_empty(ctx, ooff.data(), N, O1 * K, &cp, !want_bits, d_ooff);
+        const int sc = tsr_corpus_create_empty(ctx, ooff.data(), N, O1 * K, &cp, !want_bits, d_ooff, false);  // (tables: the setup kernel below)
         if (sc != TSR_OK) {
             (void)hipStreamSynchronize(ctx->stream);  // (the upload reads host vectors of this frame)
             return sc;
         }
     }
     if (want_bits) {
-        const int sb = tsr_corpus_alloc_bits(ctx, cp);
+        const int sb = tsr_corpus_alloc_bits(ctx, cp, false);
         if (sb != TSR_OK) {
             (void)hipStreamSynchronize(ctx->stream);
             tsr_corpus_destroy(cp);
@@ -2161,8 +2161,14 @@ TSR_API int tsr_corpus_part_features(tsr_ctx *ctx, const tsr_parts *parts, const
     int s = tsr_scratch(ctx, SLOT_AUX, (size_t)std::max<int64_t>(edges->P * N1, 1) * 4, &dA);
     if (s == TSR_OK) s = tsr_scratch(ctx, SLOT_W, (size_t)std::max<int64_t>(P_out, 1) * 12, &dRow);
     int32_t *d_src_row = (int32_t *)dRow, *d_src_lo = d_src_row + P_out, *d_src_hi = d_src_lo + P_out;
-    if (s == TSR_OK && P_out > 0)
-        s = tsr_launch_out_geometry(ctx, d_ooff, d_beg, d_n0, N, g0, P_out, d_src_row, d_src_lo, d_src_hi);
+    // the coder's work counters live in their scratch slot from here on (zeroed by the setup kernel)
+    const bool try_mfma = edges->P > 0 && parts->mode != TSR_PARTS_VALU && parts->mfma_ok;
+    void *dWork = nullptr;
+    if (s == TSR_OK && try_mfma) s = tsr_scratch(ctx, SLOT_CNT, 64, &dWork);
+    if (s == TSR_OK)  // ONE launch: source geometry, utterance tables of the new corpus, plane tails, work counters
+        s = tsr_launch_part_chain_setup(ctx, d_ooff, d_beg, d_n0, N, g0, P_out, d_src_row, d_src_lo, d_src_hi, cp->d_utt_beg, cp->d_utt_end,
+                                        reinterpret_cast<uint32_t *>(cp->d_bits), cp->d_bits ? (int64_t)cp->bit_rows * cp->bit_pw : 0,
+                                        (int64_t)cp->P * cp->bit_pw, 48 * cp->bit_pw, cp->d_bits ? cp->bit_nph : 0, (int *)dWork);
     std::vector<uint64_t> gmasks;  // graph rows as part masks (K <= 64), behind the K*K bytes
     if (s == TSR_OK && graph) {
         gmasks.assign((size_t)K, 0);
@@ -2181,13 +2187,11 @@ TSR_API int tsr_corpus_part_features(tsr_ctx *ctx, const tsr_parts *parts, const
     // mask dilation the id map is BYTES (K <= 63; 8 instead of 33 MB at config 3, written once and read once)
     const int ids8 = tsr_spread_packs_bits(N1, r0, K, Dp_new, want_bits ? pw_new * nph_new : 0) ? 1 : 0;
     bool used_mfma = false;
-    void *dWork = nullptr;
     if (s == TSR_OK && edges->P > 0) {
         int sm = TSR_ERR_UNSUPPORTED;
         if (parts->mode != TSR_PARTS_VALU && parts->mfma_ok) {
             void *dList = nullptr;
             sm = tsr_scratch(ctx, SLOT_LIST, (size_t)std::max<int64_t>(edges->P * N1, 1) * 8, &dList);
-            if (sm == TSR_OK) sm = tsr_scratch(ctx, SLOT_CNT, 64, &dWork);
             if (sm == TSR_OK)
                 sm = tsr_launch_code_parts_mfma(ctx, parts, edges->d_feats, edges->P, X1, edges->Dp, edges->d_utt_end,
                                                 threshold, fast, (int32_t *)dA, (uint32_t *)dList, (int *)dWork, ids8);

@@ -70,7 +70,7 @@ int tsr_scratch(tsr_ctx *ctx, int slot, size_t bytes, void **out);
 // buffer (a D2H straight into fresh pageable memory re-pins the pages on every call: 0.4 vs 5 ms for 3 MB).
 int tsr_download(tsr_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 int tsr_corpus_create_empty(tsr_ctx *ctx, const int64_t *frame_offsets, int64_t N, int64_t D,
-                            struct tsr_corpus **out, bool alloc_bytes = true, const int64_t *d_off_ready = nullptr);
+                            struct tsr_corpus **out, bool alloc_bytes = true, const int64_t *d_off_ready = nullptr, bool tables = true);
 
 // ---- bank ---------------------------------------------------------------------
 // Exact path: templates in groups of TSR_MG; group g holds, for every (tau, d),
@@ -206,7 +206,7 @@ static inline void tsr_bit_geometry(int64_t D, int *pw, int *nph)
 // Byte rows of a corpus that so far holds only bit rows (unpacked on the device, kept); no-op otherwise.
 int tsr_corpus_need_bytes(tsr_ctx *ctx, const struct tsr_corpus *cp);
 // Bit rows for a corpus (allocation + zeroed slack only; the caller fills them).
-int tsr_corpus_alloc_bits(tsr_ctx *ctx, struct tsr_corpus *cp);
+int tsr_corpus_alloc_bits(tsr_ctx *ctx, struct tsr_corpus *cp, bool zero_tails = true);
 
 // ---- kernels' host entry points (device pointers, enqueue on ctx->stream) -----
 // detect_exact.hip
@@ -225,6 +225,10 @@ int tsr_launch_detect_u8_single(tsr_ctx *ctx, const uint8_t *d_F, int64_t T, int
 int tsr_launch_max_detect_examples(tsr_ctx *ctx, const uint8_t *d_F, int64_t N, int64_t T,
                                    int64_t D, const double *d_LF, int64_t L,
                                    const int64_t *d_lengths, double *d_tmp, double *d_out);
+int tsr_launch_part_chain_setup(tsr_ctx *ctx, const int64_t *d_ooff, const int32_t *d_beg, const int32_t *d_n0, int64_t N, int g0,
+                                int64_t P_out, int32_t *d_src_row, int32_t *d_src_lo, int32_t *d_src_hi, int32_t *d_utt_beg,
+                                int32_t *d_utt_end, uint32_t *d_bits, int64_t plane_dwords, int64_t tail_first, int tail_count,
+                                int n_planes, int *d_work);
 int tsr_launch_out_geometry(tsr_ctx *ctx, const int64_t *d_ooff, const int32_t *d_beg, const int32_t *d_n0, int64_t N,
                             int g0, int64_t P_out, int32_t *d_src_row, int32_t *d_src_lo, int32_t *d_src_hi);
 int tsr_launch_code_parts_mag_aux(tsr_ctx *ctx, const uint8_t *d_Xe, const uint8_t *d_Xm, const uint8_t *d_Xa, int64_t X0,
