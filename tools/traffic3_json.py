@@ -17,7 +17,7 @@ for line in open(txt):
     if m and name and sec == m.group(1):
         data.setdefault(name, {})[sec] = {"calls": int(m.group(2)), "mean_KiB": float(m.group(3)), "sum_KiB": float(m.group(4))}
 # the kernels of the chain, by the stem of their names (the dilation kernel of the bit form changed during round 3)
-stems = ["code_parts_mfma_kernel", "code_parts_recheck_kernel", "spread_", "fast_bank_kernel", "frag_epilogue_kernel", "out_geometry_kernel"]
+stems = ["part_chain_setup_kernel", "code_parts_mfma_kernel", "code_parts_recheck_kernel", "spread_", "fast_bank_kernel", "frag_epilogue_kernel", "out_geometry_kernel"]
 chain = [k for st in stems for k in data if st in k]
 front = next(v for k, v in data.items() if "code_parts_mfma_kernel" in k)["FETCH_SIZE"]["calls"]   # front-end calls in the run
 per = {}
@@ -26,8 +26,8 @@ for k in chain:
     if k not in data:
         continue
     f, w = data[k].get("FETCH_SIZE", {"sum_KiB": 0, "calls": 0}), data[k].get("WRITE_SIZE", {"sum_KiB": 0, "calls": 0})
-    if "fast_bank" in k or "frag_epilogue" in k:      # bank passes: per pass = 6 phase launches (+ epilogue), several passes per front-end call
-        passes = f["calls"] / (6.0 if "fast_bank" in k else 1.0)
+    if "fast_bank" in k or "frag_epilogue" in k:      # bank passes (several per front-end call): one epilogue each; the phases share a launch since the middle of round 3
+        passes = float(next(v for kk, v in data.items() if "frag_epilogue" in kk)["FETCH_SIZE"]["calls"])
         rd, wr = 2 * f["sum_KiB"] * 1024 / passes, w["sum_KiB"] * 1024 / passes
     else:
         rd, wr = 2 * f["sum_KiB"] * 1024 / front, w["sum_KiB"] * 1024 / front
