@@ -1098,22 +1098,18 @@ TSR_API int tsr_corpus_classify_isolated(tsr_ctx *ctx, const tsr_bank *bank, con
         on_mfma = ctx->exact_mfma_state > 0;
     }
     TSR_TRY(tsr_corpus_need_bytes(ctx, cp));
-    void *d_all = nullptr, *d_win = nullptr, *d_res = nullptr, *d_items = nullptr, *d_bgd = nullptr;
+    // Everything the kernels read goes up in ONE copy (background vector | window starts | window ends | tables of the
+    // kernel) and the three result arrays come back in one: a pageable copy costs its fixed 10-20 us whatever its size.
+    void *d_all = nullptr, *d_res = nullptr, *d_up = nullptr;
     TSR_TRY(tsr_scratch(ctx, SLOT_OUT, (size_t)bank->M * NW * 4, &d_all));
-    TSR_TRY(tsr_scratch(ctx, SLOT_AUX, (size_t)W * 16, &d_win));
     TSR_TRY(tsr_scratch(ctx, SLOT_AUX2, (size_t)W * 16, &d_res));
-    TSR_TRY(tsr_scratch(ctx, SLOT_IN, (size_t)bank->D * 4, &d_bgd));
-    int64_t *d_starts = (int64_t *)d_win, *d_ends = d_starts + W;
     int64_t *d_loc = (int64_t *)d_res;
     float *d_score = (float *)(d_loc + W);
     int32_t *d_tid = (int32_t *)(d_score + W);
-    TSR_HIP(hipMemcpyAsync(d_bgd, bgd, (size_t)bank->D * 4, hipMemcpyHostToDevice, ctx->stream));
-    TSR_HIP(hipMemcpyAsync(d_starts, starts.data(), (size_t)W * 8, hipMemcpyHostToDevice, ctx->stream));
-    TSR_HIP(hipMemcpyAsync(d_ends, ends.data(), (size_t)W * 8, hipMemcpyHostToDevice, ctx->stream));
-    std::vector<tsr_iso_pair> tiles;   // (kept alive until the stream is synchronised below)
-    std::vector<int32_t> tile_kr;
-    std::vector<int64_t> it;
-    std::vector<int32_t> left;
+    const size_t off_bgd = 0, off_starts = ((size_t)bank->D * 4 + 15) / 16 * 16, off_ends = off_starts + (size_t)W * 8,
+                 off_tab = off_ends + (size_t)W * 8;  // (all multiples of 8; the tables start 16-byte aligned: W * 16 behind off_starts)
+    std::vector<uint8_t> up;   // (kept alive until the stream is synchronised below)
+    auto put = [&](size_t off, const void *src, size_t bytes) { memcpy(up.data() + off, src, bytes); };
     if (on_mfma) {
         // pairs of consecutive positions, bucketed by padding pattern: physical rows [k, k + r) of the pair are real
         int RMAX = 1;
@@ -1128,24 +1124,35 @@ TSR_API int tsr_corpus_classify_isolated(tsr_ctx *ctx, const tsr_bank *bank, con
             return k * (RMAX + 1) + r;
         };
         std::vector<int64_t> cnt((size_t)NB + 1, 0);
+        std::vector<int32_t> pat;   // the bucket of every pair, in the order of the second pass
+        pat.reserve((size_t)(NW + W) / 2 + 1);
         for (int64_t w = 0; w < W; ++w)
-            for (int32_t t = 0; t < n_valid[w]; t += 2) ++cnt[(size_t)pattern(w, t)];
+            for (int32_t t = 0; t < n_valid[w]; t += 2) {
+                const int b = pattern(w, t);
+                pat.push_back(b);
+                ++cnt[(size_t)b];
+            }
         std::vector<int64_t> at((size_t)NB + 1, 0);   // first tile row of a bucket (buckets padded to whole tiles of 16 pairs)
         int64_t n_rows = 0;
         for (int b = 0; b < NB; ++b) {
             at[(size_t)b] = n_rows;
             n_rows += (cnt[(size_t)b] + 15) / 16 * 16;
         }
-        tsr_iso_pair filler;
-        filler.f0 = 0;
-        filler.item = -1;
-        filler.left = 0;
-        tiles.assign((size_t)n_rows, filler);
-        tile_kr.assign((size_t)(n_rows / 16) * 2, 0);
-        std::vector<int64_t> put(at);
+        const int64_t n_tiles = n_rows / 16;
+        const size_t off_kr = off_tab + (size_t)n_rows * sizeof(tsr_iso_pair);
+        up.resize(off_kr + (size_t)n_tiles * 8 + 16);
+        tsr_iso_pair *tiles = reinterpret_cast<tsr_iso_pair *>(up.data() + off_tab);
+        int32_t *tile_kr = reinterpret_cast<int32_t *>(up.data() + off_kr);
+        for (int64_t x = 0; x < n_rows; ++x) {
+            tiles[x].f0 = 0;
+            tiles[x].item = -1;
+            tiles[x].left = 0;
+        }
+        std::vector<int64_t> nxt(at);
+        size_t ip = 0;
         for (int64_t w = 0; w < W; ++w)
             for (int32_t t = 0; t < n_valid[w]; t += 2) {
-                tsr_iso_pair &q = tiles[(size_t)put[(size_t)pattern(w, t)]++];
+                tsr_iso_pair &q = tiles[(size_t)nxt[(size_t)pat[ip++]]++];
                 q.f0 = first[w] + t;
                 q.item = (int32_t)(starts[(size_t)w] + t);
                 q.left = (rows[w] - t) | (t + 1 < n_valid[w] ? (1 << 30) : 0);
@@ -1157,18 +1164,21 @@ TSR_API int tsr_corpus_classify_isolated(tsr_ctx *ctx, const tsr_bank *bank, con
                 for (int64_t x = row; x < row + 16; ++x)   // filler rows shadow the tile's first pair (its frames are loaded, nothing is stored)
                     if (tiles[(size_t)x].item < 0) tiles[(size_t)x].f0 = tiles[(size_t)row].f0;
             }
-        const int64_t n_tiles = n_rows / 16;
+        put(off_bgd, bgd, (size_t)bank->D * 4);
+        put(off_starts, starts.data(), (size_t)W * 8);
+        put(off_ends, ends.data(), (size_t)W * 8);
         void *d_wb = nullptr;
-        TSR_TRY(tsr_scratch(ctx, SLOT_W, (size_t)n_rows * sizeof(tsr_iso_pair) + (size_t)n_tiles * 8 + 64, &d_items));
+        TSR_TRY(tsr_scratch(ctx, SLOT_W, up.size(), &d_up));
         TSR_TRY(tsr_scratch(ctx, SLOT_RAW, (size_t)(bank->wm_total4 + 128) * 16, &d_wb));
-        tsr_iso_pair *d_pairs = (tsr_iso_pair *)d_items;
-        int32_t *d_kr = (int32_t *)(d_pairs + n_rows);
-        TSR_HIP(hipMemcpyAsync(d_pairs, tiles.data(), (size_t)n_rows * sizeof(tsr_iso_pair), hipMemcpyHostToDevice, ctx->stream));
-        TSR_HIP(hipMemcpyAsync(d_kr, tile_kr.data(), (size_t)n_tiles * 8, hipMemcpyHostToDevice, ctx->stream));
-        TSR_TRY(tsr_launch_isolated_mfma(ctx, bank, cp->d_feats, cp->Dp, (const float *)d_bgd, d_pairs, d_kr, n_tiles, NW, d_wb, (float *)d_all));
+        TSR_HIP(hipMemcpyAsync(d_up, up.data(), up.size(), hipMemcpyHostToDevice, ctx->stream));
+        const uint8_t *du = static_cast<const uint8_t *>(d_up);
+        TSR_TRY(tsr_launch_isolated_mfma(ctx, bank, cp->d_feats, cp->Dp, (const float *)(du + off_bgd), (const tsr_iso_pair *)(du + off_tab),
+                                         (const int32_t *)(du + off_kr), n_tiles, NW, d_wb, (float *)d_all));
     } else {
-        it.resize((size_t)NW * 3);
-        left.resize((size_t)NW);
+        const size_t off_left = off_tab + (size_t)NW * 24;
+        up.resize(off_left + (size_t)NW * 4 + 16);
+        int64_t *it = reinterpret_cast<int64_t *>(up.data() + off_tab);
+        int32_t *left = reinterpret_cast<int32_t *>(up.data() + off_left);
         for (int64_t w = 0; w < W; ++w)
             for (int32_t t = 0; t < n_valid[w]; ++t) {
                 const size_t i = (size_t)(starts[(size_t)w] + t);
@@ -1177,21 +1187,26 @@ TSR_API int tsr_corpus_classify_isolated(tsr_ctx *ctx, const tsr_bank *bank, con
                 it[(size_t)2 * NW + i] = real_hi[w];
                 left[i] = rows[w] - t;
             }
-        TSR_TRY(tsr_scratch(ctx, SLOT_W, (size_t)NW * 28, &d_items));
-        int64_t *d_first = (int64_t *)d_items;
-        int32_t *d_left = (int32_t *)(d_first + 3 * NW);
-        TSR_HIP(hipMemcpyAsync(d_first, it.data(), (size_t)NW * 24, hipMemcpyHostToDevice, ctx->stream));
-        TSR_HIP(hipMemcpyAsync(d_left, left.data(), (size_t)NW * 4, hipMemcpyHostToDevice, ctx->stream));
-        TSR_TRY(tsr_launch_isolated_windows(ctx, bank, cp->d_feats, cp->Dp, (const float *)d_bgd, d_first, d_first + NW,
-                                            d_first + 2 * NW, d_left, NW, (float *)d_all));
+        put(off_bgd, bgd, (size_t)bank->D * 4);
+        put(off_starts, starts.data(), (size_t)W * 8);
+        put(off_ends, ends.data(), (size_t)W * 8);
+        TSR_TRY(tsr_scratch(ctx, SLOT_W, up.size(), &d_up));
+        TSR_HIP(hipMemcpyAsync(d_up, up.data(), up.size(), hipMemcpyHostToDevice, ctx->stream));
+        const uint8_t *du = static_cast<const uint8_t *>(d_up);
+        const int64_t *d_first = (const int64_t *)(du + off_tab);
+        TSR_TRY(tsr_launch_isolated_windows(ctx, bank, cp->d_feats, cp->Dp, (const float *)(du + off_bgd), d_first, d_first + NW,
+                                            d_first + 2 * NW, (const int32_t *)(du + off_left), NW, (float *)d_all));
     }
-    TSR_TRY(tsr_launch_window_argmax(ctx, (const float *)d_all, NW, (int)bank->M, d_starts, d_ends, W, d_score, d_loc, d_tid));
-    std::vector<int64_t> loc64((size_t)W);
-    TSR_HIP(hipMemcpyAsync(score, d_score, (size_t)W * 4, hipMemcpyDeviceToHost, ctx->stream));
-    TSR_HIP(hipMemcpyAsync(loc64.data(), d_loc, (size_t)W * 8, hipMemcpyDeviceToHost, ctx->stream));
-    TSR_HIP(hipMemcpyAsync(template_id, d_tid, (size_t)W * 4, hipMemcpyDeviceToHost, ctx->stream));
+    const uint8_t *du = static_cast<const uint8_t *>(d_up);
+    TSR_TRY(tsr_launch_window_argmax(ctx, (const float *)d_all, NW, (int)bank->M, (const int64_t *)(du + off_starts),
+                                     (const int64_t *)(du + off_ends), W, d_score, d_loc, d_tid));
+    std::vector<uint8_t> res((size_t)W * 16);   // [loc W x 8][score W x 4][template W x 4], as the kernel leaves them
+    TSR_HIP(hipMemcpyAsync(res.data(), d_res, res.size(), hipMemcpyDeviceToHost, ctx->stream));
     TSR_HIP(hipStreamSynchronize(ctx->stream));
-    for (int64_t w = 0; w < W; ++w) loc[w] = (int32_t)(loc64[(size_t)w] - starts[(size_t)w]);
+    const int64_t *loc64 = reinterpret_cast<const int64_t *>(res.data());
+    memcpy(score, res.data() + (size_t)W * 8, (size_t)W * 4);
+    memcpy(template_id, res.data() + (size_t)W * 12, (size_t)W * 4);
+    for (int64_t w = 0; w < W; ++w) loc[w] = (int32_t)(loc64[w] - starts[(size_t)w]);
     return TSR_OK;
 }
 
