@@ -434,6 +434,26 @@ def test_very_long_filters_keep_16_bit_weights(mods, oracle):
     assert rel_err(fast, exact) <= TOL
 
 
+def test_wide_rows_k_phases_and_column_groups_in_one_launch(mods, oracle):
+    """D = 1150 (36 K-blocks: three K-phases) x 20 templates of up to 40 taps (several column groups): the two-limb
+    kernel's blocks are (phase, segment, column group) of ONE launch and the fragments of a template meet in the
+    epilogue; three limbs keep their launch per phase.  Both against the oracle, scores and per-template maps."""
+    tsr_hip = mods[3]
+    from tsr_hip import synth
+    c = synth.corpus(77, N=4, T=[150, 0, 90, 333], F=23, E=50, M=20, L=[40, 7, 33, 25] * 5)
+    feats, offs = c["feats"], c["offsets"]
+    bank = tsr_hip.Bank(c["bank"])
+    so, ao = oracle.score_corpus(feats, offs, c["bank"])
+    se, ae = bank.score(feats, offs, flags=tsr_hip.TSR_EXACT)
+    assert np.array_equal(se, so) and np.array_equal(ae, ao)
+    alle = bank.score_all(feats, offs, flags=tsr_hip.TSR_EXACT)
+    for flags in (tsr_hip.TSR_FAST, tsr_hip.TSR_FAST | tsr_hip.TSR_W24):
+        sf, af = bank.score(feats, offs, flags=flags)
+        assert rel_err(sf, so) <= TOL
+        assert rel_err(bank.score_all(feats, offs, flags=flags), alle) <= TOL
+        assert np.array_equal(sf, bank.score(feats, offs, flags=flags)[0])      # integer sums: the same bits every time
+
+
 # ---- multi-GPU: the one collective of the path, for real (RCCL, one rank on this box's GPU) ----------
 def test_rccl_bank_broadcast_single_rank(mods, oracle):
     """tsr_dist_unique_id -> tsr_dist_init(nranks=1) -> tsr_bank_broadcast(root 0) -> same scores ->
