@@ -89,6 +89,9 @@ __device__ __forceinline__ int med3(int a, int b, int c)
     return d;
 }
 
+#ifndef TSR_PM_ABL
+#define TSR_PM_ABL 0   // development ablations (never set in the shipped build): 1 keys, 2 MFMAs, 4 operand refetch, 8 staging, 16 finish
+#endif
 // FAST: code_parts_fast's slot 0 (the sum of all part scores) is tracked as well.
 template <int NKB, bool FAST>
 __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
@@ -97,10 +100,9 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, half = lane >> 5;
     const int row_bytes = (a.CH + a.P0 - 1) * a.Dp;
-    uint8_t *rows = smem;
-    int32_t *kcl = reinterpret_cast<int32_t *>(smem + row_bytes + kPad);  // [2][2][16]
-    int32_t *livel = kcl + 64;                                             // [CH]: the frame takes patches
-    int32_t *chunkl = livel + a.CH;
+    const int buf_bytes = row_bytes + kPad;                                // one staged chunk (two buffers: the next chunk is copied while this one is coded)
+    int32_t *kcl = reinterpret_cast<int32_t *>(smem + 2 * buf_bytes);      // [2][2][16]
+    int32_t *livel = kcl + 64;                                             // [2][CH]: the frame takes patches
 
     // weights: register-stationary for the life of the workgroup
     i32x4 W[2][NKB][2];
@@ -124,35 +126,61 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
     const i32x16 *const kc1 = reinterpret_cast<const i32x16 *>(kcl + (half * 2 + 1) * 16);
 
     const int64_t body = a.P * (int64_t)a.Dp;
-    const int nloc = a.CH * a.N1;  // live locations of a chunk, frame-major: location ll = frame * N1 + bin
-    const int ntiles = (nloc + 31) / 32;
     const int dS = a.S - a.N1;                                     // position of location ll in frame fl: ll + fl * dS
     const int adv_fl = (32 * kWaves) / a.N1, adv_j = (32 * kWaves) % a.N1;  // a wave's next tile is 32 * kWaves locations on
     const bool wide = a.K > 56;  // part slots 56..62 in use (the keys of registers 12..15 of M-tile 1 count)
 
-    for (;;) {
-        __syncthreads();  // previous chunk fully consumed (and kcl visible the first time)
-        if (tid == 0) chunkl[0] = atomicAdd(a.work, 1);
-        __syncthreads();
-        const int chunk = chunkl[0];
-        if (chunk >= a.nchunks) break;  // uniform: every wave leaves together
-        const int64_t f0 = (int64_t)chunk * a.CH;
-        {  // stage the chunk: (CH + P0 - 1) rows with every byte x 64, zeros behind the corpus
-            const int64_t g0 = f0 * a.Dp;
-            for (int off = tid * 16; off < row_bytes + kPad; off += kWG * 16) {
-                i32x4 v = {0, 0, 0, 0};
-                if (off < row_bytes && g0 + off + 16 <= body) v = *reinterpret_cast<const i32x4 *>(a.X + g0 + off);
-                *reinterpret_cast<i32x4 *>(rows + off) = v << 6;  // bytes are 0 / 1: no carry between them
-            }
-            // a frame takes patches when the whole patch lies inside its utterance
-            if (tid < a.CH) livel[tid] = (f0 + tid < a.P && f0 + tid + a.P0 <= (int64_t)a.utt_end[f0 + tid]) ? 1 : 0;
+    // A workgroup owns a contiguous range of frames (P split evenly over the grid: two workgroups on every CU run the
+    // same number of tiles -- chunks drawn from a counter left the last ones to a few workgroups, 13 % of the kernel)
+    // and walks it in chunks of CH frames: while chunk j is coded out of one LDS buffer, chunk j + 1 is copied into
+    // the other, one 16-byte unit per thread and tile (the load is issued in front of a tile's matrix instructions and
+    // committed -- every byte x 64 -- behind them).
+    const int copy_units = buf_bytes >> 4;
+    const int64_t f_begin = a.P * (int64_t)blockIdx.x / (int64_t)gridDim.x, f_end = a.P * ((int64_t)blockIdx.x + 1) / (int64_t)gridDim.x;
+    if (f_begin >= f_end) return;  // uniform
+    auto valid_bytes = [&](int64_t f_first) -> int {  // bytes of a chunk's rows that lie inside the corpus (zeros behind them)
+        const int64_t left = body - f_first * a.Dp;
+        return (int)(left < 0 ? 0 : (left < row_bytes ? left : row_bytes));
+    };
+    {  // the workgroup's first chunk: staged at once
+        const uint8_t *src = a.X + f_begin * a.Dp;
+        const int lim = valid_bytes(f_begin);
+        for (int u = tid; u < copy_units; u += kWG) {
+            i32x4 v = {0, 0, 0, 0};
+            if (u * 16 + 16 <= lim) v = *reinterpret_cast<const i32x4 *>(src + u * 16);
+            *reinterpret_cast<i32x4 *>(smem + u * 16) = v << 6;  // bytes are 0 / 1: no carry between them
         }
-        __syncthreads();
+        // a frame takes patches when the whole patch lies inside its utterance
+        if (tid < a.CH) livel[tid] = (f_begin + tid < a.P && f_begin + tid + a.P0 <= (int64_t)a.utt_end[min(f_begin + tid, a.P - 1)]) ? 1 : 0;
+    }
+    __syncthreads();  // (kcl visible as well)
+    for (int64_t f0 = f_begin, cur = 0; f0 < f_end; f0 += a.CH, cur ^= 1) {
+        const int64_t fn = f0 + a.CH;
+        const bool has_next = fn < f_end && !(TSR_PM_ABL & 8);
+        const int nloc = (int)min((int64_t)a.CH, f_end - f0) * a.N1;  // live locations of the chunk, frame-major: location ll = frame * N1 + bin
+        const int ntiles = (nloc + 31) / 32;
+        uint8_t *const rows = smem + cur * buf_bytes, *const rows_n = smem + (cur ^ 1) * buf_bytes;
+        const int32_t *const livec = livel + cur * a.CH;
+        const uint8_t *const src_n = a.X + fn * a.Dp;
+        const int lim_n = has_next ? valid_bytes(fn) : 0;
+        int uend_n = 0;  // utt_end of the next chunk's frame tid: asked for now, used behind the tiles
+        if (has_next && tid < a.CH && fn + tid < a.P) uend_n = a.utt_end[fn + tid];
+        int cu = has_next ? tid : copy_units;  // this thread's next unit of the copy
+        auto copy_load = [&]() -> i32x4 {
+            i32x4 v = {0, 0, 0, 0};
+            if (cu < copy_units && cu * 16 + 16 <= lim_n) v = *reinterpret_cast<const i32x4 *>(src_n + cu * 16);
+            return v;
+        };
+        auto copy_commit = [&](const i32x4 &v) {
+            if (cu < copy_units) *reinterpret_cast<i32x4 *>(rows_n + cu * 16) = v << 6;
+            cu += kWG;
+        };
         const unsigned loc0 = (unsigned)(f0 * a.N1);  // (P * N1 < 2^31: checked at launch)
 
         int best = INT32_MIN, second = INT32_MIN;
         float vsum = 0.0f;
         auto slot = [&](const i32x16 (&acc)[2], int i) {
+            if ((TSR_PM_ABL & 1) && i != 3) return;
             const int key = (int)(((unsigned)acc[1][i] << 8) + (unsigned)acc[0][i]);  // one v_lshl_add_u32
             second = med3(best, second, key);
             best = max(best, key);
@@ -160,7 +188,8 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
         };
         // everything behind the second M-tile of the tile at locations ll (frame fl): margin test, list or id.
         // v_permlane32_swap(x, x) = {x of lane & 31, x of lane | 32} in every lane.
-        auto finish = [&](int ll, int fl, int cnt_own) {
+        auto finish = [&](int ll, int live_fl, int cnt_own) {  // live_fl: livel[] of the location's frame, fetched a half-tile ago
+            if (TSR_PM_ABL & 16) return;
             const auto bs = __builtin_amdgcn_permlane32_swap(best, best, false, false);
             const auto ss = __builtin_amdgcn_permlane32_swap(second, second, false, false);
             const auto cs = __builtin_amdgcn_permlane32_swap(cnt_own, cnt_own, false, false);
@@ -169,7 +198,7 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
             const int msecond = max(min((int)bs[0], (int)bs[1]), max((int)ss[0], (int)ss[1]));
             const int vbest = mbest >> 6;
             const int window = (int)count + 2;
-            const bool live = ll < nloc && livel[fl] != 0;
+            const bool live = ll < nloc && live_fl != 0;
             const bool coded = count >= a.threshold;
             bool flag = live && coded && (vbest - (msecond >> 6) <= window);
             bool full = false;
@@ -202,6 +231,7 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
         // reduced and the operands of the wave's next tile are fetched).  Each low-limb accumulator is re-armed with
         // its start keys straight from LDS as soon as its last key has been taken.
         constexpr int SL = NKB > 3 ? NKB - 2 : NKB;  // step A: K-block steps that carry keys (the finish follows them)
+        constexpr int SB = NKB > 1 ? NKB - 1 : NKB;  // step B: K-block steps that carry keys
         i32x16 accA[2], accB[2];
         i32x4 bf[NKB];
         int tile = wave;
@@ -230,13 +260,18 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
             accB[0] = *kc1;
         }
         bool have_prev = false;
-        int ll_fin = 0, fl_fin = 0;  // the tile whose M-tile 1 is in accB
+        int ll_fin = 0, live_fin = 0;  // the tile whose M-tile 1 is in accB: its locations, the live flag of their frames
         for (; tile < ntiles; tile += kWaves) {
+            const i32x4 cv = copy_load();  // (a unit of the next chunk rides through this tile)
             // ---- step A
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
+                if (TSR_PM_ABL & 2) {
+                    asm volatile("" : "+v"(accA[1]), "+v"(accA[0]) : "v"(bf[kb]), "v"(W[0][kb][0]), "v"(W[0][kb][1]));
+                } else {
                 accA[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(W[0][kb][1], bf[kb], kb ? accA[1] : (i32x16){}, 0, 0, 0);
                 accA[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(W[0][kb][0], bf[kb], accA[0], 0, 0, 0);
+                }
                 if (have_prev) {
 #pragma unroll
                     for (int e = 0; e < 12; ++e)
@@ -249,7 +284,7 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
                     if (kb == (SL < NKB ? SL : NKB - 1)) {
                         const int cnt_own = (accB[0][15] - kOnesKey) >> 6;
                         accB[0] = *kc1;
-                        finish(ll_fin, fl_fin, cnt_own);
+                        finish(ll_fin, live_fin, cnt_own);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -259,7 +294,7 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
             second = INT32_MIN;
             vsum = 0.0f;
             ll_fin = ll;
-            fl_fin = fl;
+            live_fin = livec[ll < nloc ? fl : 0];  // (lands under this step's matrix instructions)
             if (tile + kWaves < ntiles) {  // (the last tile fetches itself again)
                 ll += 32 * kWaves;
                 fl += adv_fl;
@@ -272,26 +307,37 @@ __global__ __launch_bounds__(kWG, 2) void code_parts_mfma_kernel(const PmArgs a)
             const uint8_t *xn = patch_addr();
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
+                if (TSR_PM_ABL & 2) {
+                    asm volatile("" : "+v"(accB[1]), "+v"(accB[0]) : "v"(bf[kb]), "v"(W[1][kb][0]), "v"(W[1][kb][1]));
+                } else {
                 accB[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(W[1][kb][1], bf[kb], kb ? accB[1] : (i32x16){}, 0, 0, 0);
                 accB[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(W[1][kb][0], bf[kb], accB[0], 0, 0, 0);
+                }
+                if (!(TSR_PM_ABL & 4))
                 {  // this K-block's operand of the wave's next tile
                     const i32x2 b0 = *reinterpret_cast<const i32x2 *>(xn + boff[kb][0]);
                     const i32x2 b1 = *reinterpret_cast<const i32x2 *>(xn + boff[kb][1]);
                     bf[kb] = (i32x4){b0.x, b0.y, b1.x, b1.y};
                 }
+                // (the keys leave the last K-block step free: the accumulator's start keys, read from LDS behind its last key,
+                //  then have a whole step to arrive before M-tile 0 of the next tile accumulates onto them)
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    if (e * NKB / 16 == kb) slot(accA, e);
-                if (kb == NKB - 1) accA[0] = *kc0;
+                    if (e * SB / 16 == kb) slot(accA, e);
+                if (kb == SB - 1) accA[0] = *kc0;
                 __builtin_amdgcn_sched_barrier(0);
             }
+            copy_commit(cv);
             have_prev = true;
         }
         if (have_prev) {  // the wave's last tile: nothing left to overlap
 #pragma unroll
             for (int e = 0; e < 16; ++e) slot(accB, e);
-            finish(ll_fin, fl_fin, (accB[0][15] - kOnesKey) >> 6);
+            finish(ll_fin, live_fin, (accB[0][15] - kOnesKey) >> 6);
         }
+        while (cu < copy_units) copy_commit(copy_load());  // what the tiles did not carry (few tiles per wave, or none)
+        if (has_next && tid < a.CH) livel[(cur ^ 1) * a.CH + tid] = (fn + tid < a.P && fn + tid + a.P0 <= (int64_t)uend_n) ? 1 : 0;
+        __syncthreads();  // this buffer is done with, the other one complete
     }
 }
 
@@ -422,7 +468,7 @@ int launch_nkb2(tsr_ctx *ctx, const PmArgs &a, size_t lds)
 {
     TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(code_parts_mfma_kernel<NKB, FAST>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int grid = std::min(a.nchunks, 2 * std::max(ctx->cus, 1));
+    const int grid = std::min(a.nchunks, 2 * std::max(ctx->cus, 1));  // frames split evenly over the grid, walked in chunks of CH
     hipLaunchKernelGGL((code_parts_mfma_kernel<NKB, FAST>), dim3((unsigned)grid), dim3(kWG), lds, ctx->stream, a);
     TSR_HIP(hipGetLastError());
     return TSR_OK;
@@ -563,9 +609,9 @@ int tsr_launch_code_parts_mfma(tsr_ctx *ctx, const tsr_parts *p, const uint8_t *
     const int S = Dp / 8;
     int CH = 0;
     size_t lds = 0;
-    for (int ch : {64, 32, 16}) {
-        const size_t need = (size_t)(ch + p->P0 - 1) * Dp + kPad + 256 + (size_t)ch * 4 + 16;
-        if (need <= 40 * 1024 || (ch == 16 && need <= 64 * 1024)) {
+    for (int ch : {64, 32, 16}) {  // two chunk buffers per workgroup, two workgroups per CU where they fit
+        const size_t need = 2 * ((size_t)(ch + p->P0 - 1) * Dp + kPad) + 256 + (size_t)2 * ch * 4 + 32;
+        if (need <= 76 * 1024 || (ch == 16 && need <= 150 * 1024)) {
             CH = ch;
             lds = need;
             break;

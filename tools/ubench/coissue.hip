@@ -3,6 +3,7 @@
 //   MODE 1: waves 0..W/2-1 run pure MFMAs, waves W/2.. run pure VALU (F adds per step)
 //   MODE 2: as 0, fillers = F/2 x (v_lshl_add + ds_add_u32) pairs
 //   MODE 3: as 1, partner runs (v_lshl_add + ds_add_u32) pairs
+//   MODE 4: as 2, plus one ds_read_b128 per step whose result is the MFMAs' A operand two steps later (an operand queue)
 // WAVES = 4 (one per SIMD) or 8 (two per SIMD: w and w+4 share a SIMD).  Prints cycles per step per wave class.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -23,16 +24,22 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k(int steps, unsigned l
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = lane + i;
     unsigned *cell = ring + wave * 512 + lane;
-    const bool mfma_wave = (MODE == 0 || MODE == 2) ? true : wave < WAVES / 2;
-    const bool fill_wave = (MODE == 0 || MODE == 2) ? true : wave >= WAVES / 2;
+    const bool mfma_wave = (MODE == 0 || MODE == 2 || MODE == 4) ? true : wave < WAVES / 2;
+    const bool fill_wave = (MODE == 0 || MODE == 2 || MODE == 4) ? true : wave >= WAVES / 2;
+    i32x4 q0 = a, q1 = a;
     unsigned long long t0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     for (int s = 0; s < steps; ++s) {
+        if (MODE == 4) {  // operand queue: the fragment read two steps ago feeds this step
+            a = q0;
+            q0 = q1;
+            q1 = *reinterpret_cast<const i32x4 *>(ring + ((s * 64 + lane * 4) & 2047));
+        }
         if (mfma_wave) {
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc0, 0, 0, 0);
         }
         if (fill_wave) {
-            if (MODE == 0 || MODE == 1) {
+            if (MODE == 0 || MODE == 1) {  // (MODE 4 takes the pairs below)
 #pragma unroll
                 for (int i = 0; i < F; ++i) v[i & 7] = v[i & 7] * 3 + s;  // independent chains (v_mad / lshl_add)
             } else {
@@ -100,6 +107,10 @@ int main()
     run<2, 8, 4>("2 MFMA + F/2 (lshl_add, ds_add), same wave", d_out, d_sink);
     run<2, 4, 8>("2 MFMA + F/2 (lshl_add, ds_add), every wave", d_out, d_sink);
     run<2, 8, 8>("2 MFMA + F/2 (lshl_add, ds_add), every wave", d_out, d_sink);
+    run<4, 2, 4>("2 MFMA + ds_read_b128 + F/2 (lshl_add, ds_add), same wave", d_out, d_sink);
+    run<4, 4, 4>("2 MFMA + ds_read_b128 + F/2 (lshl_add, ds_add), same wave", d_out, d_sink);
+    run<4, 6, 4>("2 MFMA + ds_read_b128 + F/2 (lshl_add, ds_add), same wave", d_out, d_sink);
+    run<4, 4, 8>("2 MFMA + ds_read_b128 + F/2 (lshl_add, ds_add), every wave", d_out, d_sink);
     run<3, 8, 8>("w<4: 2 MFMA | w>=4: F/2 (lshl_add, ds_add)", d_out, d_sink);
     run<3, 16, 8>("w<4: 2 MFMA | w>=4: F/2 (lshl_add, ds_add)", d_out, d_sink);
     return 0;
