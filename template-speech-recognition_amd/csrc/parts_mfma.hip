@@ -42,8 +42,8 @@
 // dealt out between the K-block steps -- the vector work rides in the shadow of the wave's own
 // matrix instructions instead of alternating with them.
 //
-// Frames are staged through LDS in chunks of CH frames (+ P0 - 1 rows of overlap); chunks are
-// handed out by an atomic counter (persistent workgroups, 2 per CU).
+// Frames are staged through LDS in chunks of CH frames (+ P0 - 1 rows of overlap), two buffers: a workgroup (2 per CU)
+// owns an even share of the corpus' frames and copies its next chunk while it codes the current one.
 #include "tsr_internal.h"
 
 #include <cmath>
@@ -73,7 +73,7 @@ struct PmArgs {
     unsigned threshold;
     float o0_const, o0_slack;  // code_parts_fast: slot 0 in units (see host prep)
     int n_inv;                 // empty part slots (incl. the row of ones)
-    int *work;                 // [0] chunk counter, [1] list length
+    int *work;                 // [1] list length ([0] unused since the workgroups own fixed frame ranges)
     int32_t *argmax;           // [P][N1]
     int ids8;                  // the map is written as bytes (K <= 63: the dilation kernel of the corpus chain reads them so)
     uint32_t *list;            // [n][2]: location, full (slot 0 of code_parts_fast in play)
