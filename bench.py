@@ -366,7 +366,7 @@ def roofline_of(mode, per_launch_s, frames, traffic):
 def stored_traffic(mode):
     """HBM bytes per launch from the PMC passes committed under profiles/ (collected by tools/traffic.sh on
     the > L3 working set, gfx950 corrections applied) -- NOT measured in this run."""
-    for name in ("r02_traffic_%s.json" % mode, "traffic_%s.json" % mode):
+    for name in ("r03_traffic_%s.json" % mode, "r02_traffic_%s.json" % mode, "traffic_%s.json" % mode):  # newest round first
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             j = json.load(open(p))
