@@ -296,11 +296,12 @@ __global__ __launch_bounds__(256) void iso_mfma_kernel(const uint8_t *__restrict
                                                        const f32x4 *__restrict__ wm, const f32x4 *__restrict__ wb,
                                                        const int64_t *__restrict__ gm_off, const int32_t *__restrict__ gm_rows,
                                                        const int32_t *__restrict__ Lm, const float *__restrict__ cf, int M, int64_t NW,
-                                                       float *__restrict__ out)
+                                                       float *__restrict__ out, const int *__restrict__ n_tiles_dev)
 {
     const int lane = threadIdx.x & 63;
     const int64_t unit = __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6));
     if (unit >= n_units) return;
+    if (n_tiles_dev && unit >= (int64_t)n_tiles_dev[0] * n_groups) return;  // (tables made on the device: the grid covers their upper bound)
     const int64_t tile = unit / n_groups;
     const int g = (int)(unit - tile * n_groups);
     const int i = lane & 15, kk = lane >> 4;
@@ -349,9 +350,182 @@ __global__ __launch_bounds__(256) void iso_mfma_kernel(const uint8_t *__restrict
 }
 }  // namespace
 
+// ---- the tile tables of a call, made on the device.  A pair is two consecutive searched positions of a window; its
+// bucket is its padding pattern (k, r): physical rows [k, k + r) real.  count -> scan (buckets padded to whole tiles of 16
+// pairs, (k, r) of every tile) -> scatter (a block reserves its share of every bucket with one atomic) -> fillers.
+namespace {
+constexpr int kIsoBlock = 256;
+constexpr int kIsoMaxBuckets = 2048;  // (RMAX + 1)^2 <= 45^2
+
+struct IsoWin {  // per-window geometry as tsr_corpus_classify_isolated receives it, plus prefix sums
+    const int64_t *first, *real_lo, *real_hi, *starts, *pair_start;  // [W] ... pair_start [W + 1]
+    const int32_t *rows, *n_valid;
+    int64_t W, NP;
+    int RMAX;
+};
+
+__device__ __forceinline__ void iso_pair_of(const IsoWin &g, int64_t i, int64_t &w, int32_t &t, int &bucket)
+{
+    int64_t lo = 0, hi = g.W;  // last w with pair_start[w] <= i
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (g.pair_start[mid] <= i)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    w = lo;
+    t = (int32_t)(2 * (i - g.pair_start[lo]));
+    const int64_t f0 = g.first[lo] + t;
+    int k = (int)min(max(g.real_lo[lo] - f0, (int64_t)0), (int64_t)g.RMAX);
+    const int e = (int)min(max(g.real_hi[lo] - f0, (int64_t)0), (int64_t)g.RMAX);
+    const int r = max(e - k, 0);
+    if (r == 0) k = 0;
+    bucket = k * (g.RMAX + 1) + r;
+}
+
+__global__ __launch_bounds__(kIsoBlock) void iso_count_kernel(const IsoWin g, int NB, int *__restrict__ cnt)
+{
+    __shared__ int h[kIsoMaxBuckets];
+    for (int b = threadIdx.x; b < NB; b += kIsoBlock) h[b] = 0;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * kIsoBlock + threadIdx.x;
+    if (i < g.NP) {
+        int64_t w;
+        int32_t t;
+        int b;
+        iso_pair_of(g, i, w, t, b);
+        atomicAdd(&h[b], 1);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < NB; b += kIsoBlock)
+        if (h[b]) atomicAdd(&cnt[b], h[b]);
+}
+
+// one block: first row of every bucket, the tile count, (k, r) of every tile (a tile's bucket: the last one that starts at or
+// in front of its first row -- empty buckets share their successor's start); the fill counters start at zero
+__global__ __launch_bounds__(1024) void iso_scan_kernel(int NB, int RMAX, const int *__restrict__ cnt, int *__restrict__ at, int *__restrict__ fill,
+                                                        int32_t *__restrict__ tile_kr, int *__restrict__ n_tiles)
+{
+    __shared__ int part[1024];
+    __shared__ int at_s[kIsoMaxBuckets];
+    const int per = (NB + 1023) / 1024, b0 = threadIdx.x * per;
+    int sum = 0;
+    for (int b = b0; b < min(b0 + per, NB); ++b) sum += (cnt[b] + 15) / 16 * 16;
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // inclusive scan of the threads' sums
+        const int v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int row = part[threadIdx.x] - sum;
+    for (int b = b0; b < min(b0 + per, NB); ++b) {
+        at[b] = row;
+        at_s[b] = row;
+        fill[b] = 0;
+        row += (cnt[b] + 15) / 16 * 16;
+    }
+    const int nt = part[1023] >> 4;
+    if (threadIdx.x == 1023) n_tiles[0] = nt;
+    __syncthreads();
+    for (int tile = threadIdx.x; tile < nt; tile += 1024) {
+        int lo = 0, hi = NB;  // last b with at_s[b] <= 16 tile
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (at_s[mid] <= 16 * tile)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        tile_kr[2 * tile] = lo / (RMAX + 1);
+        tile_kr[2 * tile + 1] = lo % (RMAX + 1);
+    }
+}
+
+__global__ __launch_bounds__(kIsoBlock) void iso_scatter_kernel(const IsoWin g, int NB, const int *__restrict__ at, int *__restrict__ fill,
+                                                                tsr_iso_pair *__restrict__ tiles)
+{
+    __shared__ int h[kIsoMaxBuckets];  // the block's pairs per bucket, then the block's first slot in the bucket
+    for (int b = threadIdx.x; b < NB; b += kIsoBlock) h[b] = 0;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * kIsoBlock + threadIdx.x;
+    int64_t w = 0;
+    int32_t t = 0;
+    int b = 0, rank = 0;
+    const bool on = i < g.NP;
+    if (on) {
+        iso_pair_of(g, i, w, t, b);
+        rank = atomicAdd(&h[b], 1);
+    }
+    __syncthreads();
+    for (int bb = threadIdx.x; bb < NB; bb += kIsoBlock)
+        if (h[bb]) h[bb] = atomicAdd(&fill[bb], h[bb]);
+    __syncthreads();
+    if (on) {
+        tsr_iso_pair q;
+        q.f0 = g.first[w] + t;
+        q.item = (int32_t)(g.starts[w] + t);
+        q.left = (g.rows[w] - t) | (t + 1 < g.n_valid[w] ? (1 << 30) : 0);
+        tiles[at[b] + h[b] + rank] = q;
+    }
+}
+
+// the rows behind a bucket's pairs, up to the end of its last tile, shadow that tile's first pair (frames loaded, nothing stored)
+__global__ __launch_bounds__(kIsoBlock) void iso_filler_kernel(int NB, const int *__restrict__ cnt, const int *__restrict__ at,
+                                                               tsr_iso_pair *__restrict__ tiles)
+{
+    const int b = blockIdx.x * kIsoBlock + threadIdx.x;
+    if (b >= NB) return;
+    const int end = at[b] + (cnt[b] + 15) / 16 * 16;
+    for (int x = at[b] + cnt[b]; x < end; ++x) {
+        tsr_iso_pair q;
+        q.f0 = tiles[x & ~15].f0;
+        q.item = -1;
+        q.left = 0;
+        tiles[x] = q;
+    }
+}
+}  // namespace
+
+// d_geo: first | real_lo | real_hi | starts (i64 [W] each) | pair_start (i64 [W + 1]) | rows | n_valid (i32 [W] each), as
+// tsr_corpus_classify_isolated uploads them; d_work: 2 NB + 1 ints + the tile (k, r) pairs; tiles: rows_bound pairs.
+int tsr_launch_isolated_tables(tsr_ctx *ctx, const int64_t *d_geo, int64_t W, int64_t NP, int RMAX, int *d_work, tsr_iso_pair *d_tiles,
+                               int64_t tiles_bound, const int32_t **d_tile_kr, const int **d_n_tiles)
+{
+    const int NB = (RMAX + 1) * (RMAX + 1);
+    if (NB > kIsoMaxBuckets) return TSR_ERR_UNSUPPORTED;
+    IsoWin g;
+    g.first = d_geo;
+    g.real_lo = d_geo + W;
+    g.real_hi = d_geo + 2 * W;
+    g.starts = d_geo + 3 * W;
+    g.pair_start = d_geo + 4 * W;
+    g.rows = reinterpret_cast<const int32_t *>(d_geo + 5 * W + 1);
+    g.n_valid = g.rows + W;
+    g.W = W;
+    g.NP = NP;
+    g.RMAX = RMAX;
+    int *cnt = d_work, *at = cnt + NB, *fill = at + NB, *n_tiles = fill + NB;
+    int32_t *tile_kr = n_tiles + 1;
+    TSR_HIP(hipMemsetAsync(cnt, 0, (size_t)NB * 4, ctx->stream));
+    const unsigned blocks = (unsigned)((NP + kIsoBlock - 1) / kIsoBlock);
+    hipLaunchKernelGGL(iso_count_kernel, dim3(blocks), dim3(kIsoBlock), 0, ctx->stream, g, NB, cnt);
+    hipLaunchKernelGGL(iso_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, NB, RMAX, (const int *)cnt, at, fill, tile_kr, n_tiles);
+    hipLaunchKernelGGL(iso_scatter_kernel, dim3(blocks), dim3(kIsoBlock), 0, ctx->stream, g, NB, (const int *)at, fill, d_tiles);
+    hipLaunchKernelGGL(iso_filler_kernel, dim3((unsigned)((NB + kIsoBlock - 1) / kIsoBlock)), dim3(kIsoBlock), 0, ctx->stream, NB, (const int *)cnt,
+                       (const int *)at, d_tiles);
+    TSR_HIP(hipGetLastError());
+    (void)tiles_bound;
+    *d_tile_kr = tile_kr;
+    *d_n_tiles = n_tiles;
+    return TSR_OK;
+}
+
 int tsr_launch_isolated_mfma(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *d_X, int Dp, const float *d_bgd,
                              const tsr_iso_pair *d_pairs, const int32_t *d_tile_kr, int64_t n_tiles, int64_t NW, void *d_wb_scratch,
-                             float *d_out)
+                             float *d_out, const int *d_n_tiles)
 {
     if (!bank->d_Wm || Dp != bank->wm_Dp || bank->wm_total4 <= 0) return TSR_ERR_UNSUPPORTED;
     if (n_tiles <= 0) return TSR_OK;
@@ -362,7 +536,7 @@ int tsr_launch_isolated_mfma(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *
     const int64_t n_units = n_tiles * bank->n_groups;
     hipLaunchKernelGGL(iso_mfma_kernel, dim3((unsigned)((n_units + 3) / 4)), dim3(256), 0, ctx->stream, d_X, Dp, d_pairs, d_tile_kr, n_units,
                        (int)bank->n_groups, reinterpret_cast<const f32x4 *>(bank->d_Wm), (const f32x4 *)wb, bank->d_gm_off, bank->d_gm_rows,
-                       bank->d_L, bank->d_cf, (int)bank->M, NW, d_out);
+                       bank->d_L, bank->d_cf, (int)bank->M, NW, d_out, d_n_tiles);
     TSR_HIP(hipGetLastError());
     return TSR_OK;
 }

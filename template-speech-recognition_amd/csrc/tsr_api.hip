@@ -1111,69 +1111,45 @@ TSR_API int tsr_corpus_classify_isolated(tsr_ctx *ctx, const tsr_bank *bank, con
     std::vector<uint8_t> up;   // (kept alive until the stream is synchronised below)
     auto put = [&](size_t off, const void *src, size_t bytes) { memcpy(up.data() + off, src, bytes); };
     if (on_mfma) {
-        // pairs of consecutive positions, bucketed by padding pattern: physical rows [k, k + r) of the pair are real
+        // pairs of consecutive positions, bucketed by padding pattern (physical rows [k, k + r) of the pair real) ON THE DEVICE:
+        // the windows' geometry goes up (first | real_lo | real_hi | starts | pair prefix | rows | n_valid), four small
+        // kernels count, scan, scatter and fill the tiles (detect_exact_mfma.hip); the matrix-core kernel's grid covers the
+        // upper bound of the tile count and reads the count itself
         int RMAX = 1;
         for (int32_t r : bank->gm_rows_h) RMAX = std::max(RMAX, (int)r);
         const int NB = (RMAX + 1) * (RMAX + 1);
-        auto pattern = [&](int64_t w, int32_t t) -> int {   // bucket of the pair that starts at position t of window w
-            const int64_t f0 = first[w] + t;
-            int k = (int)std::min<int64_t>(std::max<int64_t>(real_lo[w] - f0, 0), RMAX);
-            const int e = (int)std::min<int64_t>(std::max<int64_t>(real_hi[w] - f0, 0), RMAX);
-            const int r = std::max(e - k, 0);
-            if (r == 0) k = 0;
-            return k * (RMAX + 1) + r;
-        };
-        std::vector<int64_t> cnt((size_t)NB + 1, 0);
-        std::vector<int32_t> pat;   // the bucket of every pair, in the order of the second pass
-        pat.reserve((size_t)(NW + W) / 2 + 1);
-        for (int64_t w = 0; w < W; ++w)
-            for (int32_t t = 0; t < n_valid[w]; t += 2) {
-                const int b = pattern(w, t);
-                pat.push_back(b);
-                ++cnt[(size_t)b];
-            }
-        std::vector<int64_t> at((size_t)NB + 1, 0);   // first tile row of a bucket (buckets padded to whole tiles of 16 pairs)
-        int64_t n_rows = 0;
-        for (int b = 0; b < NB; ++b) {
-            at[(size_t)b] = n_rows;
-            n_rows += (cnt[(size_t)b] + 15) / 16 * 16;
-        }
-        const int64_t n_tiles = n_rows / 16;
-        const size_t off_kr = off_tab + (size_t)n_rows * sizeof(tsr_iso_pair);
-        up.resize(off_kr + (size_t)n_tiles * 8 + 16);
-        tsr_iso_pair *tiles = reinterpret_cast<tsr_iso_pair *>(up.data() + off_tab);
-        int32_t *tile_kr = reinterpret_cast<int32_t *>(up.data() + off_kr);
-        for (int64_t x = 0; x < n_rows; ++x) {
-            tiles[x].f0 = 0;
-            tiles[x].item = -1;
-            tiles[x].left = 0;
-        }
-        std::vector<int64_t> nxt(at);
-        size_t ip = 0;
-        for (int64_t w = 0; w < W; ++w)
-            for (int32_t t = 0; t < n_valid[w]; t += 2) {
-                tsr_iso_pair &q = tiles[(size_t)nxt[(size_t)pat[ip++]]++];
-                q.f0 = first[w] + t;
-                q.item = (int32_t)(starts[(size_t)w] + t);
-                q.left = (rows[w] - t) | (t + 1 < n_valid[w] ? (1 << 30) : 0);
-            }
-        for (int b = 0; b < NB; ++b)
-            for (int64_t row = at[(size_t)b]; row < at[(size_t)b] + (cnt[(size_t)b] + 15) / 16 * 16; row += 16) {
-                tile_kr[(size_t)(row / 16) * 2] = b / (RMAX + 1);
-                tile_kr[(size_t)(row / 16) * 2 + 1] = b % (RMAX + 1);
-                for (int64_t x = row; x < row + 16; ++x)   // filler rows shadow the tile's first pair (its frames are loaded, nothing is stored)
-                    if (tiles[(size_t)x].item < 0) tiles[(size_t)x].f0 = tiles[(size_t)row].f0;
-            }
+        const size_t off_geo = off_tab;   // (16-byte aligned)
+        const size_t geo_bytes = (size_t)(5 * W + 1) * 8 + (size_t)2 * W * 4;
+        up.resize(off_geo + geo_bytes + 16);
+        int64_t *gq = reinterpret_cast<int64_t *>(up.data() + off_geo);
+        memcpy(gq, first, (size_t)W * 8);
+        memcpy(gq + W, real_lo, (size_t)W * 8);
+        memcpy(gq + 2 * W, real_hi, (size_t)W * 8);
+        memcpy(gq + 3 * W, starts.data(), (size_t)W * 8);
+        int64_t *ps = gq + 4 * W;
+        ps[0] = 0;
+        for (int64_t w = 0; w < W; ++w) ps[w + 1] = ps[w] + (n_valid[w] + 1) / 2;
+        const int64_t NP = ps[W];
+        int32_t *g32 = reinterpret_cast<int32_t *>(gq + 5 * W + 1);
+        memcpy(g32, rows, (size_t)W * 4);
+        memcpy(g32 + W, n_valid, (size_t)W * 4);
         put(off_bgd, bgd, (size_t)bank->D * 4);
         put(off_starts, starts.data(), (size_t)W * 8);
         put(off_ends, ends.data(), (size_t)W * 8);
-        void *d_wb = nullptr;
+        const int64_t tiles_bound = (NP + (int64_t)15 * std::min<int64_t>(NB, NP)) / 16 + 1;
+        void *d_wb = nullptr, *d_tiles = nullptr, *d_work = nullptr;
         TSR_TRY(tsr_scratch(ctx, SLOT_W, up.size(), &d_up));
         TSR_TRY(tsr_scratch(ctx, SLOT_RAW, (size_t)(bank->wm_total4 + 128) * 16, &d_wb));
+        TSR_TRY(tsr_scratch(ctx, SLOT_AUX, (size_t)tiles_bound * 16 * sizeof(tsr_iso_pair), &d_tiles));
+        TSR_TRY(tsr_scratch(ctx, SLOT_IN, ((size_t)3 * NB + 4 + (size_t)2 * tiles_bound) * 4, &d_work));
         TSR_HIP(hipMemcpyAsync(d_up, up.data(), up.size(), hipMemcpyHostToDevice, ctx->stream));
         const uint8_t *du = static_cast<const uint8_t *>(d_up);
-        TSR_TRY(tsr_launch_isolated_mfma(ctx, bank, cp->d_feats, cp->Dp, (const float *)(du + off_bgd), (const tsr_iso_pair *)(du + off_tab),
-                                         (const int32_t *)(du + off_kr), n_tiles, NW, d_wb, (float *)d_all));
+        const int32_t *d_kr = nullptr;
+        const int *d_nt = nullptr;
+        TSR_TRY(tsr_launch_isolated_tables(ctx, (const int64_t *)(du + off_geo), W, NP, RMAX, (int *)d_work, (tsr_iso_pair *)d_tiles, tiles_bound,
+                                           &d_kr, &d_nt));
+        TSR_TRY(tsr_launch_isolated_mfma(ctx, bank, cp->d_feats, cp->Dp, (const float *)(du + off_bgd), (const tsr_iso_pair *)d_tiles, d_kr,
+                                         tiles_bound, NW, d_wb, (float *)d_all, d_nt));
     } else {
         const size_t off_left = off_tab + (size_t)NW * 24;
         up.resize(off_left + (size_t)NW * 4 + 16);
