@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void iso_mfma_kernel(const uint8_t *__restrict
 // pairs, (k, r) of every tile) -> scatter (a block reserves its share of every bucket with one atomic) -> fillers.
 namespace {
 constexpr int kIsoBlock = 256;
-constexpr int kIsoMaxBuckets = 2048;  // (RMAX + 1)^2 <= 45^2
+constexpr int kIsoMaxBuckets = TSR_ISO_MAX_BUCKETS;  // (RMAX + 1)^2: templates of up to 62 taps (longer ones: the vector kernel)
 
 struct IsoWin {  // per-window geometry as tsr_corpus_classify_isolated receives it, plus prefix sums
     const int64_t *first, *real_lo, *real_hi, *starts, *pair_start;  // [W] ... pair_start [W + 1]

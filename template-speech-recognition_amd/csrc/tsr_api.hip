@@ -1093,7 +1093,10 @@ TSR_API int tsr_corpus_classify_isolated(tsr_ctx *ctx, const tsr_bank *bank, con
     // f32 chains matched (run here, before any scratch buffer of this call exists: it uses them itself) and the option
     // does not ask for the vector kernel; else one lane per position
     bool on_mfma = false;
-    if (bank->d_Wm && cp->Dp == bank->wm_Dp && ctx->opt_exact_kernel != TSR_EXACT_KERNEL_VALU) {
+    int iso_rmax = 1;  // physical rows a pair of positions can span: the longest template group's rows
+    for (int32_t r : bank->gm_rows_h) iso_rmax = std::max(iso_rmax, (int)r);
+    if (bank->d_Wm && cp->Dp == bank->wm_Dp && ctx->opt_exact_kernel != TSR_EXACT_KERNEL_VALU &&
+        (iso_rmax + 1) * (iso_rmax + 1) <= TSR_ISO_MAX_BUCKETS) {
         TSR_TRY(exact_mfma_probe(ctx));
         on_mfma = ctx->exact_mfma_state > 0;
     }
@@ -1115,8 +1118,7 @@ TSR_API int tsr_corpus_classify_isolated(tsr_ctx *ctx, const tsr_bank *bank, con
         // the windows' geometry goes up (first | real_lo | real_hi | starts | pair prefix | rows | n_valid), four small
         // kernels count, scan, scatter and fill the tiles (detect_exact_mfma.hip); the matrix-core kernel's grid covers the
         // upper bound of the tile count and reads the count itself
-        int RMAX = 1;
-        for (int32_t r : bank->gm_rows_h) RMAX = std::max(RMAX, (int)r);
+        const int RMAX = iso_rmax;
         const int NB = (RMAX + 1) * (RMAX + 1);
         const size_t off_geo = off_tab;   // (16-byte aligned)
         const size_t geo_bytes = (size_t)(5 * W + 1) * 8 + (size_t)2 * W * 4;

@@ -249,7 +249,8 @@ struct tsr_iso_pair {   // one row of a tile: the positions item and item + 1 of
 int tsr_launch_isolated_mfma(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *d_X, int Dp, const float *d_bgd,
                              const tsr_iso_pair *d_pairs, const int32_t *d_tile_kr, int64_t n_tiles, int64_t NW, void *d_wb_scratch,
                              float *d_out, const int *d_n_tiles = nullptr);
-// the tile tables made on the device from the windows' geometry (detect_exact_mfma.hip)
+// the tile tables made on the device from the windows' geometry (detect_exact_mfma.hip); buckets = (longest template group + 2)^2
+#define TSR_ISO_MAX_BUCKETS 4096
 int tsr_launch_isolated_tables(tsr_ctx *ctx, const int64_t *d_geo, int64_t W, int64_t NP, int RMAX, int *d_work, tsr_iso_pair *d_tiles,
                                int64_t tiles_bound, const int32_t **d_tile_kr, const int **d_n_tiles);
 int tsr_launch_isolated_windows(tsr_ctx *ctx, const tsr_bank *bank, const uint8_t *d_X, int Dp, const float *d_bgd,

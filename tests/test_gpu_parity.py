@@ -789,6 +789,37 @@ def test_classification_golden(mods, isolated):
     assert (ids != 3).all()          # template 3 duplicates template 1: the earlier one keeps the tie
 
 
+@pytest.mark.parametrize("lengths", [[48, 20, 33], [70, 12]])
+def test_isolated_classification_long_templates(mods, oracle, lengths):
+    """Isolated windows with templates of 48 taps (2 500 padding patterns: the device-side tile tables at their wider
+    bucket range) and of 70 taps (more patterns than the tables hold: the vector kernel takes the call); both
+    against the oracle and against each other's kernel."""
+    tsr_hip = mods[3]
+    import template_speech_rec.get_train_data as gtrd
+    from tsr_hip import synth
+    rng = np.random.default_rng(7 + len(lengths))
+    q = synth.background(rng, (9, 8)).astype(np.float32)
+    bank = synth.bank(rng, q, lengths)
+    utts = [synth.features(rng, T, q) for T in (150, 97, 260)]
+    fl = []
+    for E in utts:
+        b = [0]
+        while b[-1] < E.shape[0]:
+            b.append(min(E.shape[0], b[-1] + int(rng.integers(2, 40))))
+        fl.append(np.array(b, np.int64))
+    res = {}
+    for name, opt in (("auto", tsr_hip.TSR_OPT_AUTO), ("valu", tsr_hip.TSR_EXACT_KERNEL_VALU)):
+        with tsr_hip.default_ctx().option(tsr_hip.TSR_OPT_EXACT_KERNEL, opt):
+            res[name] = gtrd.get_classify_scores_E(utts, fl, bank, bgd=q, isolated=True)
+    for a, b in zip(res["auto"], res["valu"]):
+        assert np.array_equal(a, b)
+    for n, (E, f) in enumerate(zip(utts, fl)):
+        z = [np.zeros((1, len(f)), dt) for dt in (np.float32, np.int16, np.uint16, np.uint16)]
+        oracle.compute_isolated_classification_E(E, None, f.copy(), 0, z[0], z[3], z[2], z[1], bank, q)
+        for a, b in zip(res["auto"], z):
+            assert np.array_equal(a[n, :len(f) - 1], b[0, :len(f) - 1]), n
+
+
 def test_classification_random_vs_oracle(mods, oracle):
     tsr_hip = mods[3]
     import template_speech_rec.get_train_data as gtrd
