@@ -53,11 +53,17 @@ def launch_ranks(n, argv):
     """Parent of a self-launched N-GPU run: one child process per GPU with RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_ADDR / MASTER_PORT set (what torch.distributed.run would export), the same argv, a fresh shared
     secret for the host control plane.  This process imports neither tsr_hip nor torch and makes no GPU call.
-    Rank 0's stdout is relayed line by line; the others' stdout goes to stderr.  If a rank fails, the rest get
-    20 s to notice (they leave through the control plane's own errors) and are then terminated by PID."""
+    Rank 0's stdout is relayed line by line by a reader thread; the others' stdout goes to stderr.  The watchdog
+    runs beside the relay from the start: once any rank has failed, the rest get TSR_LAUNCH_GRACE_S (20 s) to
+    leave through the control plane's own errors and are then terminated by PID -- also when rank 0 sits inside a
+    collective and never closes its stdout; TSR_LAUNCH_DEADLINE_S (3600 s) bounds the whole run the same way.
+    Children are only ever started fresh; nothing is re-exec'ed."""
     import secrets
     import socket
     import subprocess
+    import threading
+    grace = float(os.environ.get("TSR_LAUNCH_GRACE_S", "20"))
+    deadline = time.time() + float(os.environ.get("TSR_LAUNCH_DEADLINE_S", "3600"))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -70,15 +76,26 @@ def launch_ranks(n, argv):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
-    try:
-        for line in procs[0].stdout:      # rank 0 prints the one JSON line
+
+    def relay():
+        for line in procs[0].stdout:      # rank 0 prints the one JSON line; ends when rank 0's stdout closes
             sys.stdout.write(line)
             sys.stdout.flush()
+
+    reader = threading.Thread(target=relay, daemon=True)
+    reader.start()
+    gave_up = None
+    try:
         failed_at = None
         while any(p.poll() is None for p in procs):
+            now = time.time()
             if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
-                failed_at = time.time()
-            if failed_at is not None and time.time() - failed_at > 20.0:
+                failed_at = now
+            if failed_at is not None and now - failed_at > grace:
+                gave_up = "a rank failed and the others did not leave within %.0f s" % grace
+                break
+            if now > deadline:
+                gave_up = "the run passed its deadline (TSR_LAUNCH_DEADLINE_S)"
                 break
             time.sleep(0.05)
     finally:
@@ -91,9 +108,13 @@ def launch_ranks(n, argv):
             except subprocess.TimeoutExpired:
                 p.kill()
                 p.wait()
+        reader.join(5)
     codes = [p.returncode for p in procs]
+    if gave_up is not None:
+        sys.stderr.write("bench.py launcher: %s; exit codes %s\n" % (gave_up, codes))
     worst = max((c for c in codes), key=lambda c: (c != 0, abs(c)))
-    return worst if worst >= 0 else 128 - worst
+    worst = worst if worst >= 0 else 128 - worst
+    return worst if worst != 0 or gave_up is None else 1
 
 
 if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _wanted_gpus(sys.argv[1:]) > 1:
@@ -377,6 +398,11 @@ def stored_traffic(mode):
 
 def dry_run_ranks(world, rank):
     """The host side of an N-rank run with the GPU work left out (tests/test_bench_launch_cpu.py)."""
+    if os.environ.get("TSR_DRY_RUN_SCENARIO") == "rank1_dies_rank0_hangs":
+        # what a crashed rank looks like to the launcher while rank 0 sits inside a collective: no output, no exit
+        if rank == 1:
+            raise SystemExit(7)
+        time.sleep(600)
     group = tdist.HostGroup.from_env(timeout=60) if world > 1 else tdist.HostGroup(0, 1)
     uid = tdist.exchange_unique_id(group, lambda: bytes(range(128)))
     bank = tdist.broadcast_object(group, synth.corpus(2, N=2, T=40, F=5, E=4, M=2, L=8)["bank"] if rank == 0 else None)

@@ -136,7 +136,9 @@ TSR_API int tsr_ctx_get_option(const tsr_ctx *ctx, int option, int *value)
     case TSR_OPT_EXACT_KERNEL: *value = ctx->opt_exact_kernel; return TSR_OK;
     case TSR_OPT_PART_LAYOUT: *value = ctx->opt_part_layout; return TSR_OK;
     case TSR_OPT_XCD_MAP: *value = ctx->opt_xcd_map; return TSR_OK;
-    case TSR_INFO_EXACT_MFMA: *value = ctx->exact_mfma_state; return TSR_OK;
+    case TSR_INFO_EXACT_MFMA:  // 1 trusted, -1 probe ran and differed, -2 last probe could not run (it is tried again), 0 not probed
+        *value = ctx->exact_mfma_state != 0 ? ctx->exact_mfma_state : (ctx->exact_mfma_could_not_run ? -2 : 0);
+        return TSR_OK;
     default: break;
     }
     tsr_set_error("tsr_ctx_get_option: unknown option %d", option);
@@ -819,9 +821,17 @@ static int exact_mfma_probe(tsr_ctx *ctx)
     if (bank) tsr_bank_destroy(bank);
     if (same) {
         ctx->exact_mfma_state = 1;
-    } else {
-        fprintf(stderr, "libtsr_hip: TSR_EXACT stays on the vector kernel on device %d: the matrix-core probe %s\n", ctx->device,
-                s == TSR_OK ? "did not reproduce the sequential f32 sums bit for bit" : "could not run");
+        ctx->exact_mfma_could_not_run = false;
+    } else if (s == TSR_OK) {  // both kernels ran and the sums differ: the only case that is latched
+        fprintf(stderr, "libtsr_hip: TSR_EXACT stays on the vector kernel on device %d: the matrix-core probe did not reproduce the "
+                        "sequential f32 sums bit for bit\n", ctx->device);
+    } else {  // a transient failure (allocation, launch): this pass takes the vector kernel, the next exact pass probes again
+        if (!ctx->exact_mfma_could_not_run)
+            fprintf(stderr, "libtsr_hip: the matrix-core probe of TSR_EXACT could not run on device %d (%s); this pass uses the vector "
+                            "kernel, the next one probes again\n", ctx->device, tsr_last_error());
+        ctx->exact_mfma_state = 0;
+        ctx->exact_mfma_could_not_run = true;
+        tsr_set_error("%s", "");  // the probe's failure is not the caller's: TSR_OK is returned with a clean error string
     }
     return TSR_OK;  // (never an error of the caller's pass: the vector kernel is always there)
 }
@@ -897,7 +907,10 @@ static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp,
 
 TSR_API int tsr_corpus_score(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int flags)
 {
-    return corpus_score_impl(ctx, bank, cp, flags, nullptr);
+    if (cp) cp->scored = false;  // (a failed pass may have written part of the arrays)
+    const int s = corpus_score_impl(ctx, bank, cp, flags, nullptr);
+    if (s == TSR_OK && cp) cp->scored = true;
+    return s;
 }
 
 TSR_API int tsr_corpus_score_all(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, int flags, float *per_template)
@@ -915,6 +928,7 @@ TSR_API int tsr_corpus_score_all(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus 
 TSR_API int tsr_corpus_download(tsr_ctx *ctx, const tsr_corpus *cp, float *scores, int32_t *ids)
 {
     TSR_REQUIRE(ctx && cp, "tsr_corpus_download: null pointer");
+    TSR_REQUIRE(cp->scored || cp->P == 0, "tsr_corpus_download: this corpus has not been scored (tsr_corpus_score) -- its result arrays hold nothing yet");
     TSR_HIP(hipSetDevice(ctx->device));
     if (scores && cp->P) TSR_TRY(tsr_download(ctx, scores, cp->d_scores, (size_t)cp->P * 4));
     if (ids && cp->P) TSR_TRY(tsr_download(ctx, ids, cp->d_ids, (size_t)cp->P * 4));
@@ -1195,6 +1209,7 @@ static int peaks_source(tsr_ctx *ctx, const tsr_corpus *cp, const float *vals, c
                         const float **d_v, const int64_t **d_off, int64_t *total, const char *who)
 {
     TSR_REQUIRE(ctx && (cp || (vals && offsets)), "%s: need a scored corpus or host score rows", who);
+    TSR_REQUIRE(!cp || cp->scored || cp->P == 0, "%s: this corpus has not been scored (tsr_corpus_score) -- pass host score rows or score it first", who);
     TSR_HIP(hipSetDevice(ctx->device));
     const int64_t *offs = cp ? cp->offsets.data() : offsets;
     const int64_t n = cp ? cp->N : N;

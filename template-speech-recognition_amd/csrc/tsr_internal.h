@@ -63,6 +63,7 @@ struct tsr_ctx {
     // chain: 0 = not yet checked on this device, 1 = the probe matched the vector kernel bit for bit, -1 = it did not
     // (the vector kernel serves every TSR_EXACT call of this context, said once on stderr)
     int exact_mfma_state = 0;
+    bool exact_mfma_could_not_run = false;  // the last probe failed to run (state stays 0: probed again)
 };
 
 int tsr_scratch(tsr_ctx *ctx, int slot, size_t bytes, void **out);
@@ -132,6 +133,7 @@ struct tsr_corpus {
     int32_t *d_utt_beg = nullptr;    // [P] first frame of the utterance holding p
     float *d_scores = nullptr;       // [P]
     int32_t *d_ids = nullptr;        // [P]
+    bool scored = false;             // d_scores / d_ids hold the result of a max-mode scoring pass (they come from the pool uninitialised)
     std::vector<int64_t> offsets;    // host [N+1]
     // fast path: cached partition of the frame stream into per-workgroup segments
     int plan_key = 0;                // (segments, Lmax) the plan was built for

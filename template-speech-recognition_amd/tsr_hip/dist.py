@@ -340,10 +340,14 @@ class HostGroup:
         rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
         if world == 1:
             return cls(rank, world)
-        addr = _loopback(os.environ.get("MASTER_ADDR", "127.0.0.1"))
+        # The control plane is one node by construction, so the socket always binds and dials 127.0.0.1; MASTER_ADDR
+        # (the node's own name under `torchrun --standalone` / c10d rendezvous) only names the job in the rendezvous
+        # tag.  An explicit addr= given to the constructor is still held to loopback by _loopback().
+        addr = "127.0.0.1"
         if "TSR_CTRL_PORT" in os.environ:
             return cls(rank, world, addr, int(os.environ["TSR_CTRL_PORT"]), timeout=timeout)
-        tag = "%s_%s_%s" % (addr, os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"))
+        tag = "%s_%s_%s" % (os.environ.get("MASTER_ADDR", addr), os.environ.get("MASTER_PORT", "0"),
+                            os.environ.get("TORCHELASTIC_RUN_ID", "none"))
         tag = "".join(ch if ch.isalnum() or ch in "._-" else "_" for ch in tag)
         path = os.path.join(_private_dir(), "%s.port" % tag)
         return cls(rank, world, addr, 0, rendezvous_file=path, timeout=timeout)

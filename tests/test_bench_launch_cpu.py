@@ -41,3 +41,26 @@ def test_bench_parent_does_not_load_hip_or_torch():
     head = src[:src.index("import tsr_hip")]
     assert "raise SystemExit(launch_ranks(" in head          # the launch happens before the library import
     assert "import torch" not in src
+
+
+def test_bench_parent_gives_up_when_a_rank_dies_and_rank0_never_returns():
+    # rank 1 exits early, rank 0 blocks (as inside a collective) and never closes its stdout: the parent's watchdog
+    # must run beside the relay, terminate rank 0 by PID after the grace period and exit non-zero
+    import time
+    env = dict(_clean_env(), TSR_DRY_RUN_SCENARIO="rank1_dies_rank0_hangs", TSR_LAUNCH_GRACE_S="2")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-ranks"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert time.time() - t0 < 60
+    assert "a rank failed" in r.stderr
+
+
+def test_bench_parent_deadline():
+    import time
+    env = dict(_clean_env(), TSR_DRY_RUN_SCENARIO="rank1_dies_rank0_hangs", TSR_LAUNCH_GRACE_S="500",
+               TSR_LAUNCH_DEADLINE_S="3")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-ranks"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and time.time() - t0 < 60 and "deadline" in r.stderr
