@@ -70,12 +70,21 @@ enum {
  *              than 16 bits.
  *   TSR_FAST | TSR_W24: three limbs (23-bit weights, power-of-two scale),
  *              <= 2^-22 * max|W_m| per set tap, at 1.5x the matrix-core work. */
-enum { TSR_EXACT = 0, TSR_FAST = 1, TSR_W24 = 2, TSR_BF16 = 4 };
+enum { TSR_EXACT = 0, TSR_FAST = 1, TSR_W24 = 2, TSR_BF16 = 4, TSR_MX = 8 };
 /*   TSR_FAST | TSR_BF16 [| TSR_W24]: the bank as a bf16 MFMA GEMM (BASELINE configs[4]): weights rounded to bf16
  *              (relative error up to 2^-9 per weight: NOT within the 1e-4 bar) or, with TSR_W24, split into
  *              bf16 hi + lo (2^-17 per weight); f32 accumulation inside a 32-frame tile, tile sums rounded to
  *              fixed point and added as integers (order-independent, hence bit-reproducible, but not exact).
- *              Comparison variants only; D <= 384, otherwise the exact kernel serves the call. */
+ *              Comparison variants only; D <= 384, otherwise the exact kernel serves the call.
+ *   TSR_FAST | TSR_MX: 13-bit weights (|q| <= 4095, per-template scale) as three radix-16 digits, each an exact fp6
+ *              value, on the block-scaled matrix instruction (v_mfma_scale_f32_16x16x128_f8f6f4: fp4 frames x fp6
+ *              weights at four times the bf16 rate, the digits' weights 1 / 16 / 256 applied by its block scales, one
+ *              f32 accumulator holding the exact integer sum).  The bank pass is a skew-free Toeplitz product
+ *              (csrc/detect_mx.hip) and the fastest path for a bank of up to eight templates on rows of up to 512
+ *              features (BASELINE config 2); |error| <= 2^-13 * max|W_m| per SET tap in the worst case, unbiased --
+ *              observed 2e-5 relative on config 2 (scores of order 4 * 10^3), i.e. eight times TSR_FAST's figure and a
+ *              fifth of the 1e-4 bar.  Max mode only (scores + ids); other banks, all-scores passes and filters of at
+ *              most 4096 taps are served as plain TSR_FAST.  Stands alone beside TSR_FAST (not with TSR_W24 / TSR_BF16). */
 
 typedef struct tsr_ctx tsr_ctx;       /* device + stream + scratch                 */
 typedef struct tsr_bank tsr_bank;     /* device-resident template bank             */

@@ -136,6 +136,7 @@ void tsr_fast_bank_free(tsr_bank *bank)
 {
     for (int k = 0; k < 5; ++k) fast_bank_free_one(bank, k);
     bank->tap2_unsupported = false;
+    tsr_mx_bank_free(bank);
 }
 
 static uint16_t bf16_rn(float x)  // round to nearest even (finite inputs)

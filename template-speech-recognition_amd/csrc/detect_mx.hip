@@ -1,0 +1,523 @@
+// detect_mx.hip -- TSR_FAST | TSR_MX: the bank pass of a small template bank (M <= 8) on narrow feature rows as a
+// skew-free Toeplitz product on the block-scaled matrix instruction v_mfma_scale_f32_16x16x128_f8f6f4.
+// (reference: compute_likelihood_linear_filter.pyx:162-175 for the sums, get_train_data.py:962-992 for the bank epilogue)
+//
+// Formulation.  A tile is 16 *pairs* of window starts of one stream position each: row i stands for the starts
+// t0_i and t0_i + 1 (t0_i even inside its utterance), column n = 8 s + m for (shift s, template m), and
+//     acc[i][(s, m)] = sum over tap rows rho = 0 .. Lmax and features d of  X[t0_i + rho][d] * W_m[rho - s][d]
+// (weights zero outside 0 <= rho - s < L_m): the score of template m at start t0_i + s, complete in ONE accumulator
+// element -- no skew reduction, no ring, no atomics; the price is Lmax + 1 tap rows instead of Lmax.  Rows are only
+// the starts that some template can score (t <= T - Lmin), so the 31 tail frames of a 200-frame utterance cost nothing.
+//
+// Operands.  X is binary, so it is an exact fp4 (e2m1) operand: nibble 0x2 = 1.0.  The weights are fixed point with a
+// per-template scale, |q| <= 4095, split into three radix-16 digits in -16 .. 16, each an exact fp6 (e2m3) value
+// digit / 8; the instruction's block scales (E8M0, one per lane and 32 K-elements) carry 2^3, 2^7 and 2^11, so the three
+// limb products meet in ONE f32 accumulator as the exact integer sum (all partial sums are integers below 2^24).
+// fp4 x fp6 issues at four times the bf16 rate (MI355X_MICROARCH.md; tools/ubench/mx_probe.hip measured 16.4 cycles per
+// instruction and SIMD), three limbs therefore cost 0.75 of the two int8 limbs of the tap-pair kernel -- at 13 instead of
+// 16 bits of weight (include/tsr.h says what that means for the error).
+//
+// Work split.  One workgroup per CU takes MX_NT = 21 row tiles (672 window starts) and holds ALL their frames in LDS
+// as nibbles (expanded from the corpus' resident bit rows: 48 B per frame from HBM instead of 368), column-major:
+// [frame parity][16-byte chunk of the row][row] so that the 16 rows of an A fragment are 16 consecutive 16-byte slots
+// (conflict-free ds_read_b128 at any alignment when the rows per column are a multiple of 16) and a fragment's address
+// is (per-lane tile base) + (wave-uniform offset of the K-block).  The eight waves split K: wave w owns the K-blocks
+// w, w + 8, ... (a K-block = 128 features of one tap row), streams their B fragments from L2 straight into registers
+// (456 KB per workgroup, once) and walks all 21 tiles with them.  The eight partial accumulators of a tile meet once, at the
+// end, through LDS; the tile's owner applies scale, tail rule, + c and the max / first arg-max over templates.
+#include <algorithm>
+#include <cmath>
+
+#include "tsr_internal.h"
+
+namespace {
+
+using i32x8 = __attribute__((ext_vector_type(8))) int;
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+using i32x2 = __attribute__((ext_vector_type(2))) int;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int MX_NT = 21;         // row tiles per workgroup (accumulators: 4 registers each)
+constexpr int MX_WAVES = 8;
+constexpr int MX_LDS = 163840;    // the whole LDS of a CU
+constexpr int MX_MAX_KBF = 4;     // feature rows of up to 512 features
+constexpr int MX_QMAX = 4095;     // |fixed-point weight|
+
+struct MxGroup {   // one tile row: the window starts t0 and t0 + 1 of one utterance
+    int32_t v0;    // virtual position of t0 (utterances padded to even lengths: v0 is even)
+    int32_t p0;    // stream frame of t0
+    int32_t rem;   // frames the utterance has left from t0 on (T - t0)
+    int32_t pad;
+};
+struct MxCol {     // one of the 16 columns: (shift s = n >> 3, template m = n & 7)
+    float inv_scale, c;
+    int32_t L, id;
+};
+struct MxArgs {
+    const uint32_t *bits;     // [rows][DW] resident bit rows at virtual positions
+    const unsigned char *B;   // [NKB][3 limbs][1536]: 64 lanes x 16 B, then 64 lanes x 8 B
+    const int32_t *koff;      // [NKB] LDS byte offset of the K-block's A fragments
+    const MxGroup *groups;
+    const int4 *wg;           // per workgroup: first tile, tiles, first virtual row, rows to stage
+    const MxCol *cols;        // [16]
+    float *scores;
+    int32_t *ids;
+    int n_groups, NKB, KBF, NR, Lmin, idmax;
+    float cmax;
+};
+
+struct MxBank {
+    int KBF = 0, ROWS = 0, NKB = 0, NR = 0, Lmin = 0, Lmax = 0, idmax = 0;
+    float cmax = 0;
+    unsigned char *d_B = nullptr;
+    int32_t *d_koff = nullptr;
+    MxCol *d_cols = nullptr;
+};
+
+struct MxCorpus {   // derived forms of a corpus: bit rows (once), the tile plan of one (Lmin, ROWS, NR)
+    uint32_t *d_bits = nullptr;
+    int DW = 0;
+    int64_t Pv = 0, rows_alloc = 0;
+    std::vector<int64_t> voff;
+    int plan_Lmin = -1, plan_ROWS = -1, plan_NR = -1;
+    MxGroup *d_groups = nullptr;
+    int4 *d_wg = nullptr;
+    int n_groups = 0, n_wg = 0;
+    bool plan_unsupported = false;
+};
+
+__device__ __forceinline__ unsigned orderable(float x)
+{
+    unsigned u = __float_as_uint(x);
+    return u ^ ((unsigned)((int)u >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float unorderable(unsigned u)
+{
+    u ^= (~(unsigned)((int)u >> 31)) | 0x80000000u;
+    return __uint_as_float(u);
+}
+
+// bit rows at virtual positions from the resident byte rows (one-off per corpus)
+__global__ void mx_pack_bits_kernel(const uint8_t *feats, int Dp, const int64_t *off, const int64_t *voff, int64_t N, int DW,
+                                    int64_t Pv, uint32_t *bits)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Pv * DW) return;
+    const int64_t v = idx / DW;
+    const int w = (int)(idx - v * DW);
+    int64_t lo = 0, hi = N;   // last u with voff[u] <= v
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (voff[mid] <= v) lo = mid; else hi = mid;
+    }
+    const int64_t t = v - voff[lo], T = off[lo + 1] - off[lo];
+    uint32_t word = 0;
+    if (t < T) {
+        const uint8_t *row = feats + (off[lo] + t) * (int64_t)Dp;
+        for (int k = 0; k < 32; ++k) {
+            const int d = 32 * w + k;
+            if (d < Dp && row[d]) word |= 1u << k;
+        }
+    }
+    bits[idx] = word;
+}
+
+__global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int4 wg = a.wg[blockIdx.x];
+    const int tile_beg = wg.x, nt = wg.y, v_lo = wg.z, nfr = wg.w;
+    const int NR = a.NR, KBF = a.KBF, CH = 4 * KBF, DW = 4 * KBF;
+
+    // ---- B fragments of this wave's first K-block: in flight while the frames are staged ----
+    const unsigned char *bp = a.B + (size_t)wave * (3 * 1536) + lane * 16;
+    i32x4 b4[3];
+    i32x2 b2[3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        b4[l] = *reinterpret_cast<const i32x4 *>(bp + l * 1536);
+        b2[l] = *reinterpret_cast<const i32x2 *>(bp + l * 1536 + 1024 - lane * 8);
+    }
+
+    // ---- frames -> LDS: bit rows expanded to fp4 nibbles (0x2 = 1.0), column-major; lane = row, so the stores of a
+    //      wave are consecutive 16-byte slots; element 8 k + j of a 32-feature chunk is feature 4 j + k (the bank's
+    //      fragments use the same order), which makes a chunk four shift-and-mask pairs ----
+    {
+        const int nrows = (nfr + 1) >> 1;
+        const int total = 2 * KBF * nrows;
+        for (int idx = tid; idx < total; idx += MX_WAVES * 64) {
+            const int pass = idx / nrows, r = idx - pass * nrows;
+            const int plane = pass & 1, kbf = pass >> 1;
+            const int fr = 2 * r + plane;
+            u32x4 b = {0, 0, 0, 0};
+            if (fr < nfr) b = *reinterpret_cast<const u32x4 *>(a.bits + (size_t)(v_lo + fr) * DW + 4 * kbf);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned x = b[q];
+                const u32x4 o = {(x << 1) & 0x22222222u, x & 0x22222222u, (x >> 1) & 0x22222222u, (x >> 2) & 0x22222222u};
+                *reinterpret_cast<u32x4 *>(lds + ((size_t)((plane * CH + 4 * kbf + q) * NR + r) << 4)) = o;
+            }
+        }
+    }
+
+    // per-lane LDS offset of (tile j, row lane & 15), the lane's K-quarter folded in
+    int tb[MX_NT];
+#pragma unroll
+    for (int j = 0; j < MX_NT; ++j) {
+        const int gi = (tile_beg + j) * 16 + (lane & 15);
+        int v0 = v_lo;
+        if (j < nt && gi < a.n_groups) v0 = a.groups[gi].v0;
+        tb[j] = (((v0 - v_lo) >> 1) + NR * (lane >> 4)) << 4;
+    }
+    f32x4 acc[MX_NT];
+#pragma unroll
+    for (int j = 0; j < MX_NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    // ---- K loop: this wave's K-blocks over all tiles ----
+    for (int kb = wave; kb < a.NKB; kb += MX_WAVES) {
+        const int koff = a.koff[kb];
+        i32x8 B[3];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) B[l] = i32x8{b4[l][0], b4[l][1], b4[l][2], b4[l][3], b2[l][0], b2[l][1], 0, 0};
+        if (kb + MX_WAVES < a.NKB) {   // next K-block's fragments (used one iteration later)
+            const unsigned char *nb = a.B + (size_t)(kb + MX_WAVES) * (3 * 1536) + lane * 16;
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                b4[l] = *reinterpret_cast<const i32x4 *>(nb + l * 1536);
+                b2[l] = *reinterpret_cast<const i32x2 *>(nb + l * 1536 + 1024 - lane * 8);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MX_NT; ++j) {
+            const i32x4 x = *reinterpret_cast<const i32x4 *>(lds + tb[j] + koff);
+            const i32x8 A = {x[0], x[1], x[2], x[3], 0, 0, 0, 0};
+            acc[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B[0], acc[j], 4, 2, 0, 0x7f7f7f7f, 0, (int)0x82828282u);
+            acc[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B[1], acc[j], 4, 2, 0, 0x7f7f7f7f, 0, (int)0x86868686u);
+            acc[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B[2], acc[j], 4, 2, 0, 0x7f7f7f7f, 0, (int)0x8a8a8a8au);
+        }
+    }
+
+    // ---- the eight partial sums of a tile meet in LDS (the frames are done with): tile j belongs to wave j & 7 ----
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MX_NT; ++j) {
+        const int owner = j & 7;
+        if (wave != owner) {
+            const int r = wave - (wave > owner ? 1 : 0);
+            *reinterpret_cast<f32x4 *>(lds + ((size_t)(j * 7 + r) << 10) + lane * 16) = acc[j];
+        }
+    }
+    __syncthreads();
+    const int n = lane & 15, s = n >> 3, rq = lane >> 4;
+    const MxCol col = a.cols[n];
+#pragma unroll
+    for (int j = 0; j < MX_NT; ++j) {
+        if ((j & 7) != wave || j >= nt) continue;
+        f32x4 sum = acc[j];
+#pragma unroll
+        for (int r = 0; r < 7; ++r) sum += *reinterpret_cast<const f32x4 *>(lds + ((size_t)(j * 7 + r) << 10) + lane * 16);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int gi = (tile_beg + j) * 16 + 4 * rq + g;
+            MxGroup G = {0, 0, 0, 0};
+            if (gi < a.n_groups) G = a.groups[gi];
+            const bool valid = s + col.L <= G.rem;   // the window of template m at t0 + s lies inside the utterance
+            const float val = (valid ? sum[g] * col.inv_scale : 0.0f) + col.c;   // (tail rule: 0 + c_m)
+            unsigned long long key = ((unsigned long long)orderable(val) << 32) | (unsigned)~col.id;
+#pragma unroll
+            for (int x = 1; x < 8; x <<= 1) {   // max over the eight templates of this shift: highest score, lowest id on ties
+                const unsigned long long o = __shfl_xor(key, x);
+                key = o > key ? o : key;
+            }
+            if ((n & 7) == 0 && s < G.rem) {
+                a.scores[G.p0 + s] = unorderable((unsigned)(key >> 32));
+                a.ids[G.p0 + s] = (int)~(unsigned)key;
+            }
+            if (G.rem > 2 && G.rem < a.Lmin + 2) {   // last group of its utterance: the frames behind it score max_m c_m
+                for (int t = 2 + n; t < G.rem; t += 16) {
+                    a.scores[G.p0 + t] = a.cmax;
+                    a.ids[G.p0 + t] = a.idmax;
+                }
+            }
+        }
+    }
+}
+
+inline MxBank *mxb(const tsr_bank *b) { return static_cast<MxBank *>(b->mx); }
+inline MxCorpus *mxc(const tsr_corpus *c) { return static_cast<MxCorpus *>(c->mx); }
+
+int fp6_code(int d)   // digit / 8 as e2m3: magnitudes 0 .. 15 are their own code, 16 (= 2.0) is exponent 2, mantissa 0
+{
+    const int mag = d < 0 ? -d : d;
+    return (mag & 31) | (d < 0 ? 0x20 : 0);
+}
+
+}  // namespace
+
+void tsr_mx_bank_free(tsr_bank *bank)
+{
+    MxBank *mb = mxb(bank);
+    if (!mb) return;
+    (void)hipSetDevice(bank->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(mb->d_B);
+    (void)hipFree(mb->d_koff);
+    (void)hipFree(mb->d_cols);
+    delete mb;
+    bank->mx = nullptr;
+    bank->mx_unsupported = false;
+}
+
+void tsr_mx_corpus_free(tsr_corpus *cp)
+{
+    MxCorpus *mc = mxc(cp);
+    if (!mc) return;
+    (void)hipFree(mc->d_bits);
+    (void)hipFree(mc->d_groups);
+    (void)hipFree(mc->d_wg);
+    delete mc;
+    cp->mx = nullptr;
+}
+
+// The bank's fragments.  TSR_ERR_UNSUPPORTED: more than 8 templates, rows wider than 512 features, or filters so long
+// that not even one tile's frames fit the LDS image.
+static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
+{
+    if (bank->mx) return TSR_OK;
+    if (bank->mx_unsupported) return TSR_ERR_UNSUPPORTED;
+    const int M = bank->M;
+    const int64_t D = bank->D;
+    const int KBF = (int)((D + 127) / 128);
+    if (M < 1 || M > 8 || KBF > MX_MAX_KBF) {
+        bank->mx_unsupported = true;
+        return TSR_ERR_UNSUPPORTED;
+    }
+    int Lmin = bank->L[0];
+    for (int m = 0; m < M; ++m) Lmin = std::min(Lmin, bank->L[m]);
+    const int ROWS = bank->Lmax + 1, NKB = ROWS * KBF;
+    const int NR = MX_LDS / (128 * KBF) / 16 * 16;   // rows per column array: a multiple of 16 (conflict-free fragment reads)
+    if (ROWS + 34 > 2 * NR) {   // (a tile of one long utterance spans 32 + ROWS frames)
+        bank->mx_unsupported = true;
+        return TSR_ERR_UNSUPPORTED;
+    }
+    TSR_HIP(hipSetDevice(ctx->device));
+    MxBank *mb = new MxBank;
+    mb->KBF = KBF; mb->ROWS = ROWS; mb->NKB = NKB; mb->NR = NR; mb->Lmin = Lmin; mb->Lmax = bank->Lmax;
+    std::vector<MxCol> cols(16);
+    std::vector<double> scale(M);
+    std::vector<int64_t> woff(M + 1, 0);
+    for (int m = 0; m < M; ++m) woff[m + 1] = woff[m] + (int64_t)bank->L[m] * D;
+    float cmax = 0;
+    int idmax = 0;
+    for (int m = 0; m < M; ++m) {
+        double mx = 0;
+        for (int64_t i = woff[m]; i < woff[m + 1]; ++i) mx = std::max(mx, (double)fabsf(bank->W_cat[(size_t)i]));
+        scale[m] = mx > 0 ? (double)MX_QMAX / mx : 1.0;
+        const float cf = (float)bank->c[m];
+        if (m == 0 || cf > cmax) { cmax = cf; idmax = m; }
+    }
+    mb->cmax = cmax; mb->idmax = idmax;
+    for (int n = 0; n < 16; ++n) {
+        const int m = n & 7;
+        if (m < M) cols[n] = MxCol{(float)(1.0 / scale[m]), (float)bank->c[m], bank->L[m], m};
+        else cols[n] = MxCol{0.0f, -INFINITY, 1 << 30, 0x7ffffffe};
+    }
+    std::vector<unsigned char> Bf((size_t)NKB * 3 * 1536, 0);
+    std::vector<int32_t> koff(NKB);
+    const int CH = 4 * KBF;
+    for (int kb = 0; kb < NKB; ++kb) {
+        const int rho = kb / KBF, kbf = kb % KBF;
+        koff[kb] = ((rho >> 1) + NR * ((rho & 1) * CH + 4 * kbf)) << 4;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int n = lane & 15, q = lane >> 4, s = n >> 3, m = n & 7;
+            uint32_t str[3][6] = {{0}};
+            const int tau = rho - s;
+            if (m < M && tau >= 0 && tau < bank->L[m]) {
+                const float *Wrow = bank->W_cat.data() + woff[m] + (int64_t)tau * D;
+                for (int e = 0; e < 32; ++e) {
+                    const int64_t f = 128 * kbf + 32 * q + 4 * (e & 7) + (e >> 3);   // element 8 k + j = feature 4 j + k of the chunk
+                    if (f >= D) continue;
+                    const long v = lrint((double)Wrow[f] * scale[m]);
+                    const long l2 = (v + 128) >> 8;              // (arithmetic shift: floor) -16 .. 16
+                    const long r = v - 256 * l2;                 // -128 .. 127
+                    const long l1 = (r + 8) >> 4;                // -8 .. 8
+                    const long l0 = r - 16 * l1;                 // -8 .. 7
+                    const int dg[3] = {(int)l0, (int)l1, (int)l2};
+                    for (int l = 0; l < 3; ++l) {
+                        const uint32_t code = (uint32_t)fp6_code(dg[l]);
+                        const int bit = 6 * e;
+                        str[l][bit >> 5] |= code << (bit & 31);
+                        if ((bit & 31) > 26) str[l][(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+                    }
+                }
+            }
+            for (int l = 0; l < 3; ++l) {
+                unsigned char *dst = Bf.data() + ((size_t)kb * 3 + l) * 1536;
+                memcpy(dst + lane * 16, &str[l][0], 16);
+                memcpy(dst + 1024 + lane * 8, &str[l][4], 8);
+            }
+        }
+    }
+    int st = TSR_OK;
+    auto up = [&](void **d, const void *h, size_t bytes) {
+        if (st != TSR_OK) return;
+        if (hipMalloc(d, bytes) != hipSuccess || hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = TSR_ERR_HIP;
+    };
+    up(reinterpret_cast<void **>(&mb->d_B), Bf.data(), Bf.size());
+    up(reinterpret_cast<void **>(&mb->d_koff), koff.data(), koff.size() * 4);
+    up(reinterpret_cast<void **>(&mb->d_cols), cols.data(), cols.size() * sizeof(MxCol));
+    if (st == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = TSR_ERR_HIP;
+    bank->mx = mb;
+    if (st != TSR_OK) {
+        tsr_mx_bank_free(bank);
+        tsr_set_error("TSR_MX: bank upload failed");
+        return st;
+    }
+    return TSR_OK;
+}
+
+// Bit rows of the corpus at virtual positions (every utterance starts on an even row), built once.
+static int mx_corpus_bits(tsr_ctx *ctx, tsr_corpus *cp, int KBF)
+{
+    MxCorpus *mc = mxc(cp);
+    if (!mc) {
+        mc = new MxCorpus;
+        cp->mx = mc;
+    }
+    const int DW = 4 * KBF;
+    if (mc->d_bits && mc->DW == DW) return TSR_OK;
+    TSR_TRY(tsr_corpus_need_bytes(ctx, cp));
+    if (mc->d_bits) {
+        TSR_HIP(hipStreamSynchronize(ctx->stream));
+        TSR_HIP(hipFree(mc->d_bits));
+        mc->d_bits = nullptr;
+    }
+    const int64_t N = cp->N;
+    mc->voff.assign((size_t)N + 1, 0);
+    for (int64_t u = 0; u < N; ++u) mc->voff[(size_t)u + 1] = mc->voff[(size_t)u] + ((cp->offsets[(size_t)u + 1] - cp->offsets[(size_t)u] + 1) & ~(int64_t)1);
+    mc->Pv = mc->voff[(size_t)N];
+    mc->DW = DW;
+    mc->rows_alloc = mc->Pv + 2 * (MX_LDS / 128 / 16 * 16) + 2;   // read-ahead of the last workgroup: at most one LDS image of rows
+    const size_t bytes = (size_t)mc->rows_alloc * DW * 4;
+    TSR_HIP(hipMalloc(reinterpret_cast<void **>(&mc->d_bits), bytes));
+    TSR_HIP(hipMemsetAsync(mc->d_bits, 0, bytes, ctx->stream));
+    if (mc->Pv > 0) {
+        int64_t *d_tab = nullptr;
+        TSR_HIP(hipMalloc(reinterpret_cast<void **>(&d_tab), (size_t)(N + 1) * 16));
+        hipError_t e = hipMemcpyAsync(d_tab, cp->offsets.data(), (size_t)(N + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_tab + (N + 1), mc->voff.data(), (size_t)(N + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            const int64_t total = mc->Pv * DW;
+            hipLaunchKernelGGL(mx_pack_bits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, cp->d_feats, cp->Dp,
+                               d_tab, d_tab + (N + 1), N, DW, mc->Pv, mc->d_bits);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_tab);
+        if (e != hipSuccess) {
+            (void)hipFree(mc->d_bits);
+            mc->d_bits = nullptr;
+            tsr_set_error("TSR_MX: building the bit rows failed: %s", hipGetErrorString(e));
+            return TSR_ERR_HIP;
+        }
+    }
+    return TSR_OK;
+}
+
+// Groups (pairs of window starts), tiles of 16 groups, workgroups of at most MX_NT tiles whose frames fit the LDS image.
+static int mx_corpus_plan(tsr_ctx *ctx, tsr_corpus *cp, const MxBank *mb)
+{
+    MxCorpus *mc = mxc(cp);
+    if (mc->plan_Lmin == mb->Lmin && mc->plan_ROWS == mb->ROWS && mc->plan_NR == mb->NR)
+        return mc->plan_unsupported ? TSR_ERR_UNSUPPORTED : TSR_OK;
+    if (mc->d_groups || mc->d_wg) {
+        TSR_HIP(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(mc->d_groups);
+        (void)hipFree(mc->d_wg);
+        mc->d_groups = nullptr;
+        mc->d_wg = nullptr;
+    }
+    mc->plan_Lmin = mb->Lmin; mc->plan_ROWS = mb->ROWS; mc->plan_NR = mb->NR;
+    mc->plan_unsupported = false;
+    std::vector<MxGroup> groups;
+    for (int64_t u = 0; u < cp->N; ++u) {
+        const int64_t T = cp->offsets[(size_t)u + 1] - cp->offsets[(size_t)u];
+        if (T <= 0) continue;
+        const int64_t ng = (std::max<int64_t>(T - mb->Lmin + 1, 1) + 1) / 2;
+        for (int64_t g = 0; g < ng; ++g) {
+            const int64_t v0 = mc->voff[(size_t)u] + 2 * g, p0 = cp->offsets[(size_t)u] + 2 * g;
+            if (v0 > INT32_MAX - 4096 || groups.size() > (size_t)INT32_MAX / 32) {
+                mc->plan_unsupported = true;
+                return TSR_ERR_UNSUPPORTED;
+            }
+            groups.push_back(MxGroup{(int32_t)v0, (int32_t)p0, (int32_t)std::min<int64_t>(T - 2 * g, INT32_MAX), 0});
+        }
+    }
+    const int64_t n_groups = (int64_t)groups.size(), n_tiles = (n_groups + 15) / 16;
+    std::vector<int4> wgs;
+    const int64_t span_max = 2 * (int64_t)mb->NR;
+    auto span_end = [&](int64_t tile_last) {   // one past the last virtual row the tiles up to tile_last read
+        const int64_t gl = std::min<int64_t>(n_groups, (tile_last + 1) * 16) - 1;
+        return (int64_t)groups[(size_t)gl].v0 + mb->ROWS;
+    };
+    for (int64_t t = 0; t < n_tiles;) {
+        const int64_t v_lo = groups[(size_t)(t * 16)].v0;
+        int64_t cnt = 0;
+        while (cnt < MX_NT && t + cnt < n_tiles && span_end(t + cnt) - v_lo <= span_max) ++cnt;
+        if (cnt == 0) {   // not even one tile's frames fit (tiny utterances with long filters)
+            mc->plan_unsupported = true;
+            return TSR_ERR_UNSUPPORTED;
+        }
+        wgs.push_back(make_int4((int)t, (int)cnt, (int)v_lo, (int)(span_end(t + cnt - 1) - v_lo)));
+        t += cnt;
+    }
+    for (const int4 &w : wgs)
+        if ((int64_t)w.z + w.w > mc->rows_alloc) {   // (cannot happen: the slack behind the bit rows is one LDS image)
+            mc->plan_unsupported = true;
+            return TSR_ERR_UNSUPPORTED;
+        }
+    mc->n_groups = (int)n_groups;
+    mc->n_wg = (int)wgs.size();
+    if (n_groups) {
+        TSR_HIP(hipMalloc(reinterpret_cast<void **>(&mc->d_groups), groups.size() * sizeof(MxGroup)));
+        TSR_HIP(hipMalloc(reinterpret_cast<void **>(&mc->d_wg), wgs.size() * sizeof(int4)));
+        TSR_HIP(hipMemcpyAsync(mc->d_groups, groups.data(), groups.size() * sizeof(MxGroup), hipMemcpyHostToDevice, ctx->stream));
+        TSR_HIP(hipMemcpyAsync(mc->d_wg, wgs.data(), wgs.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+        TSR_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return TSR_OK;
+}
+
+// TSR_FAST | TSR_MX, max mode.  TSR_ERR_UNSUPPORTED when the bank or the corpus does not fit (the caller then takes
+// the int8 kernels).
+int tsr_launch_mx_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, float *d_scores, int32_t *d_ids)
+{
+    if (!d_scores || !d_ids) return TSR_ERR_UNSUPPORTED;
+    tsr_bank *wb = const_cast<tsr_bank *>(bank);
+    TSR_TRY(mx_bank_build(ctx, wb));
+    const MxBank *mb = mxb(bank);
+    if (cp->P == 0) return TSR_OK;
+    if (cp->P > (int64_t)INT32_MAX - 4096) return TSR_ERR_UNSUPPORTED;
+    TSR_TRY(mx_corpus_bits(ctx, cp, mb->KBF));
+    TSR_TRY(mx_corpus_plan(ctx, cp, mb));
+    const MxCorpus *mc = mxc(cp);
+    if (mc->n_wg == 0) return TSR_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mx_bank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS));
+        attr_set = true;
+    }
+    MxArgs a;
+    a.bits = mc->d_bits; a.B = mb->d_B; a.koff = mb->d_koff; a.groups = mc->d_groups; a.wg = mc->d_wg; a.cols = mb->d_cols;
+    a.scores = d_scores; a.ids = d_ids;
+    a.n_groups = mc->n_groups; a.NKB = mb->NKB; a.KBF = mb->KBF; a.NR = mb->NR; a.Lmin = mb->Lmin; a.idmax = mb->idmax; a.cmax = mb->cmax;
+    const size_t lds = std::max<size_t>((size_t)128 * mb->KBF * mb->NR, (size_t)MX_NT * 7 * 1024);
+    TSR_REQUIRE(lds <= (size_t)MX_LDS, "TSR_MX: LDS image of %zu bytes", lds);
+    hipLaunchKernelGGL(mx_bank_kernel, dim3((unsigned)mc->n_wg), dim3(MX_WAVES * 64), lds, ctx->stream, a);
+    TSR_HIP(hipGetLastError());
+    return TSR_OK;
+}

@@ -760,6 +760,7 @@ TSR_API int tsr_corpus_destroy(tsr_corpus *cp)
     dev_free(cp->d_aff);
     dev_free(cp->d_feats_bf16);
     dev_free(cp->d_planes);
+    tsr_mx_corpus_free(cp);
     delete cp;
     return TSR_OK;
 }
@@ -841,10 +842,23 @@ static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp,
 {
     TSR_REQUIRE(ctx && bank && cp, "tsr_corpus_score: null pointer");
     TSR_REQUIRE(bank->D == cp->D, "tsr_corpus_score: bank D=%lld but corpus D=%lld", (long long)bank->D, (long long)cp->D);
-    TSR_REQUIRE((flags & ~(TSR_FAST | TSR_W24 | TSR_BF16)) == 0, "tsr_corpus_score: unknown flags 0x%x", flags);
-    TSR_REQUIRE(!(flags & (TSR_W24 | TSR_BF16)) || (flags & TSR_FAST), "tsr_corpus_score: TSR_W24 / TSR_BF16 modify TSR_FAST");
+    TSR_REQUIRE((flags & ~(TSR_FAST | TSR_W24 | TSR_BF16 | TSR_MX)) == 0, "tsr_corpus_score: unknown flags 0x%x", flags);
+    TSR_REQUIRE(!(flags & (TSR_W24 | TSR_BF16 | TSR_MX)) || (flags & TSR_FAST), "tsr_corpus_score: TSR_W24 / TSR_BF16 / TSR_MX modify TSR_FAST");
+    TSR_REQUIRE(!(flags & TSR_MX) || !(flags & (TSR_W24 | TSR_BF16)), "tsr_corpus_score: TSR_MX stands alone beside TSR_FAST");
     if (cp->P == 0) return TSR_OK;
     TSR_HIP(hipSetDevice(ctx->device));
+    if (flags & TSR_MX) {
+        // 13-bit weights as three fp6 limbs on the block-scaled matrix instruction (detect_mx.hip): banks of up to eight
+        // templates on rows of up to 512 features, max mode.  Anything else -- and short filters, whose scores of order
+        // one want more than 13 bits -- is served as plain TSR_FAST.
+        flags &= ~TSR_MX;
+        int32_t Lmin = bank->Lmax;
+        for (int32_t l : bank->L) Lmin = std::min(Lmin, l);
+        if (!d_all && (int64_t)Lmin * bank->D > TSR_FAST_W24_BELOW_TAPS) {
+            const int sm = tsr_launch_mx_bank(ctx, bank, cp, cp->d_scores, cp->d_ids);
+            if (sm != TSR_ERR_UNSUPPORTED) return sm;
+        }
+    }
     // Short filters (few thousand taps) produce scores of order one, against which the 16-bit
     // quantisation noise is no longer small; their launch is latency-bound anyway, so TSR_FAST
     // takes the third limb there at no measurable cost (include/tsr.h, "at least 16-bit weights").

@@ -120,6 +120,9 @@ struct tsr_bank {
     // [4] two int8 limbs with two taps folded into K (tap2_bank_kernel, narrow feature rows)
     void *fast[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool tap2_unsupported = false;   // the kind-4 build was tried and the geometry does not fit
+    // TSR_MX (detect_mx.hip): fp6 limb fragments of the Toeplitz form, built lazily
+    void *mx = nullptr;
+    bool mx_unsupported = false;
 };
 
 struct tsr_corpus {
@@ -160,6 +163,7 @@ struct tsr_corpus {
     float *d_aff = nullptr;          // [P][aff_K]
     int64_t aff_K = 0, aff_cap = 0;  // columns in use; capacity in floats
     std::vector<double> aff_colsum;  // [aff_K] column sums of d_aff (the M-step's weights x P)
+    void *mx = nullptr;              // TSR_MX (detect_mx.hip): bit rows at even-aligned positions + the tile plan, built on first use
 };
 
 struct tsr_parts {
@@ -296,6 +300,10 @@ void tsr_fast_bank_free(tsr_bank *bank);
 int tsr_launch_tap2_bank(tsr_ctx *ctx, const tsr_bank *bank, struct tsr_corpus *cp, float *d_scores, int32_t *d_ids, float *d_all);
 int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *corpus, int flags,
                          float *d_scores, int32_t *d_ids, float *d_all);
+// detect_mx.hip
+int tsr_launch_mx_bank(tsr_ctx *ctx, const tsr_bank *bank, struct tsr_corpus *cp, float *d_scores, int32_t *d_ids);
+void tsr_mx_bank_free(tsr_bank *bank);
+void tsr_mx_corpus_free(struct tsr_corpus *cp);
 // parts.hip
 int tsr_launch_code_parts(tsr_ctx *ctx, const tsr_parts *parts, const uint8_t *d_X, int64_t X0,
                           int64_t X1, int threshold, int fast, double *d_out /*or null*/,

@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("TSR_HIP_LIB") or os.path.join(_PKG, "lib", "libtsr_hi
 
 TSR_OK, TSR_ERR_INVALID, TSR_ERR_HIP, TSR_ERR_NO_DEVICE, TSR_ERR_UNSUPPORTED, TSR_ERR_NONFINITE, \
     TSR_ERR_RCCL = range(7)
-TSR_EXACT, TSR_FAST, TSR_W24, TSR_BF16 = 0, 1, 2, 4
+TSR_EXACT, TSR_FAST, TSR_W24, TSR_BF16, TSR_MX = 0, 1, 2, 4, 8
 TSR_PARTS_AUTO, TSR_PARTS_VALU, TSR_PARTS_MFMA = 0, 1, 2
 # context options (include/tsr.h: tsr_ctx_set_option)
 TSR_OPT_FAST_KERNEL, TSR_OPT_EXACT_KERNEL, TSR_OPT_PART_LAYOUT, TSR_OPT_XCD_MAP = 1, 2, 3, 4

@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-from ._lib import TSR_BF16, TSR_EXACT, TSR_FAST, TSR_W24, check, lib, ptr  # noqa: F401
+from ._lib import TSR_BF16, TSR_EXACT, TSR_FAST, TSR_MX, TSR_W24, check, lib, ptr  # noqa: F401
 
 _default_ctx = None
 

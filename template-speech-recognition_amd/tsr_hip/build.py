@@ -8,7 +8,7 @@ PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(PKG, "lib", "obj")
 LIB = os.path.join(PKG, "lib", "libtsr_hip.so")
-SOURCES = ["tsr_api.hip", "detect_exact.hip", "detect_exact_mfma.hip", "detect_mfma.hip", "detect_mfma_i0.hip", "detect_mfma_i1.hip", "detect_mfma_i2.hip", "detect_mfma_i3.hip", "detect_mfma_i4.hip", "detect_mfma_i5.hip", "parts.hip", "parts_mfma.hip", "classify.hip", "edges.hip", "edges2.hip", "detect_mfma_bf16.hip", "detect_mfma_tap2_i0.hip", "detect_mfma_tap2_i1.hip", "detect_mfma_tap2_i2.hip"]
+SOURCES = ["tsr_api.hip", "detect_exact.hip", "detect_exact_mfma.hip", "detect_mfma.hip", "detect_mfma_i0.hip", "detect_mfma_i1.hip", "detect_mfma_i2.hip", "detect_mfma_i3.hip", "detect_mfma_i4.hip", "detect_mfma_i5.hip", "parts.hip", "parts_mfma.hip", "classify.hip", "edges.hip", "edges2.hip", "detect_mfma_bf16.hip", "detect_mfma_tap2_i0.hip", "detect_mfma_tap2_i1.hip", "detect_mfma_tap2_i2.hip", "detect_mx.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wextra", "-Wno-unused-parameter"]
 # per-source extras: matrix instructions with VGPR accumulators (with AGPR accumulators the register allocator

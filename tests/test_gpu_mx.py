@@ -1,0 +1,187 @@
+"""GPU parity tests of TSR_FAST | TSR_MX (csrc/detect_mx.hip): the bank pass as a skew-free Toeplitz product on the
+block-scaled matrix instruction, 13-bit weights as three fp6 digits.
+
+Two checkers.  (1) The oracle (the reference's f32 sums, compute_likelihood_linear_filter.pyx:162-175 + the bank epilogue
+of get_train_data.py:962-992): |a - b| <= 1e-4 max(|b|, 1) over every frame, ids equal wherever the top-2 margin is clear,
+tail frames exactly max_m c_m.  (2) An integer emulation of the kernel's own arithmetic written out here in NumPy
+(quantise with the per-template scale, exact integer window sums, one multiply, one add): the kernel's sums are exact
+integers, so it must reproduce that emulation to the last f32 rounding -- which pins the operand layout, the digit split,
+the block scales, the cross-wave reduction and the tile plan far more tightly than the 1e-4 bar can."""
+import numpy as np
+import pytest
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def tsr_hip():
+    import tsr_hip as t
+    return t
+
+
+def _emulate(feats2d, offs, bank, qmax=4095):
+    """The kernel's arithmetic: q = rint(W * qmax / max|W_m|), exact integer sums over the set taps, score =
+    f32(sum) * f32(1 / scale) + f32(c_m), zero sum where the window leaves the utterance; max over m, lowest id on ties.
+    Returns (scores f64 [P], ids, per-template values f64 [M, P], rounding slack [P])."""
+    P = int(offs[-1])
+    M = len(bank)
+    vals = np.zeros((M, P))
+    slack = np.zeros((M, P))
+    X = feats2d.astype(np.float64)
+    for m, (W, c) in enumerate(bank):
+        L = W.shape[0]
+        W2 = W.reshape(L, -1).astype(np.float64)
+        mx = np.abs(W2).max()
+        scale = qmax / mx if mx > 0 else 1.0
+        q = np.rint(W2 * scale)
+        inv = float(np.float32(1.0 / scale))
+        cf = float(np.float32(c))
+        G = X @ q.T                                   # [P, L] exact integers
+        for n in range(len(offs) - 1):
+            a, b = int(offs[n]), int(offs[n + 1])
+            T = b - a
+            raw = np.zeros(T)
+            if T >= L:
+                for tau in range(L):
+                    raw[:T - L + 1] += G[a + tau:a + tau + T - L + 1, tau]
+            vals[m, a:b] = raw * inv + cf
+            slack[m, a:b] = (np.abs(raw * inv) + abs(cf)) * 2.0 ** -22
+    ids = np.argmax(vals, axis=0)
+    return vals.max(axis=0), ids, vals, slack.max(axis=0)
+
+
+def _check(tsr_hip, oracle, c, with_oracle=True, tol=TOL):
+    feats, offs = c["feats"], c["offsets"]
+    P = int(offs[-1])
+    f2 = feats.reshape(P, -1)
+    bank = tsr_hip.Bank(c["bank"])
+    s, a = bank.score(f2, offs, flags=tsr_hip.TSR_FAST | tsr_hip.TSR_MX)
+    assert s.shape == (P,) and a.shape == (P,)
+    es, ea, vals, slack = _emulate(f2, offs, c["bank"])
+    assert np.all(np.abs(s - es) <= slack + 1e-30), float(np.max(np.abs(s - es) - slack))
+    if vals.shape[0] > 1 and P:
+        top2 = np.sort(vals, axis=0)[-2:]
+        clear = (top2[1] - top2[0]) > 4 * slack
+        assert np.array_equal(a[clear], ea[clear])
+    elif P:
+        assert np.all(a == 0)
+    if with_oracle and P:
+        so, ao = oracle.score_corpus(feats, offs, c["bank"])
+        assert rel_err(s, so) <= tol
+    bank.close()
+    return s, a
+
+
+def test_mx_is_the_matrix_instruction_kernel(tsr_hip, oracle):
+    """Config 1's geometry with eight templates: one workgroup, partially filled tiles."""
+    from tsr_hip import synth
+    c = synth.corpus(1, N=1, T=400, F=45, E=8, M=8, L=32)
+    _check(tsr_hip, oracle, c)
+
+
+@pytest.mark.parametrize("shape", [
+    dict(N=7, T=[200, 199, 33, 32, 31, 5, 64], F=45, E=8, M=8, L=32),            # odd lengths, T = L, T < L
+    dict(N=5, T=[90, 0, 61, 1, 47], F=45, E=8, M=5, L=[20, 24, 28, 32, 36]),      # an empty utterance, ragged L_m, M < 8
+    dict(N=4, T=[150, 77, 300, 41], F=16, E=8, M=8, L=40),                         # D = 128: one K-block per tap row
+    dict(N=6, T=[120, 64, 65, 66, 67, 230], F=64, E=8, M=3, L=[36, 33, 40]),       # D = 512: four K-blocks per row
+    dict(N=3, T=[500, 45, 46], F=26, E=5, M=1, L=45),                              # one template, D = 130 off every grid
+    dict(N=40, T=70, F=45, E=8, M=7, L=[32, 32, 33, 34, 35, 36, 37]),              # several workgroups' worth of short utterances
+], ids=["odd_T", "empty_utt", "D128", "D512", "M1_D130", "short_utts"])
+def test_mx_small_against_emulation_and_oracle(tsr_hip, oracle, shape):
+    from tsr_hip import synth
+    c = synth.corpus(77, **shape)
+    _check(tsr_hip, oracle, c)
+
+
+def test_mx_ties_go_to_the_lowest_id(tsr_hip, oracle):
+    from tsr_hip import synth
+    c = synth.corpus(5, N=3, T=[80, 120, 57], F=45, E=8, M=4, L=32)
+    b = list(c["bank"])
+    b[2] = b[0]            # templates 0 and 2 identical: every frame is a tie between them
+    b[3] = b[1]
+    c["bank"] = tuple(b)
+    s, a = _check(tsr_hip, oracle, c)
+    assert set(np.unique(a)) <= {0, 1}
+
+
+def test_mx_config2_all_frames(tsr_hip, oracle):
+    """BASELINE config 2 (1000 x 200 frames, D = 360, M = 8, L = 32) -- what bench.py times -- every frame against the
+    oracle and against the emulation, the tail rule, invariance to batching, and the other precisions beside it."""
+    from tsr_hip import synth
+    c = synth.corpus(2, N=1000, T=200, F=45, E=8, M=8, L=32)
+    feats, offs = c["feats"], c["offsets"]
+    P = int(offs[-1])
+    f2 = feats.reshape(P, -1)
+    bank = tsr_hip.Bank(c["bank"])
+    dc = tsr_hip.Corpus(f2, offs)
+    dc.score(bank, tsr_hip.TSR_FAST | tsr_hip.TSR_MX)
+    s, a = dc.download()
+    dc.score(bank, tsr_hip.TSR_FAST | tsr_hip.TSR_MX)       # second pass on the cached bit rows and plan
+    s1, a1 = dc.download()
+    assert np.array_equal(s, s1) and np.array_equal(a, a1)
+    so, ao = oracle.score_corpus(feats, offs, c["bank"])
+    err = rel_err(s, so)
+    assert err <= TOL, err
+    assert err <= 4e-5, err                                  # (observed 2e-5: the 13-bit weights, not a layout slip)
+    dc.score(bank, tsr_hip.TSR_EXACT)
+    se, ae = dc.download()
+    alle = dc.score_all(bank, tsr_hip.TSR_EXACT)
+    assert np.array_equal(se, so) and np.array_equal(ae, ao)
+    top2 = np.sort(alle, axis=0)[-2:]
+    clear = (top2[1] - top2[0]) > TOL * np.maximum(np.abs(top2[1]), 1.0)
+    assert np.array_equal(a[clear], ao[clear]) and clear.mean() > 0.5
+    cf = np.array([np.float32(cc) for _, cc in c["bank"]])
+    assert np.all(s.reshape(1000, 200)[:, 169:] == cf.max()) and np.all(a.reshape(1000, 200)[:, 169:] == int(np.argmax(cf)))
+    es, ea, vals, slack = _emulate(f2[:offs[40]], offs[:41], c["bank"])      # the emulation on the first 40 utterances
+    assert np.all(np.abs(s[:offs[40]] - es) <= slack)
+    s2, a2 = bank.score(f2[offs[500]:], offs[500:] - offs[500], flags=tsr_hip.TSR_FAST | tsr_hip.TSR_MX)   # second half alone
+    assert np.array_equal(s2, s[offs[500]:]) and np.array_equal(a2, a[offs[500]:])
+    dc.close()
+    bank.close()
+
+
+def test_mx_ragged_large_corpus(tsr_hip, oracle):
+    """P > 60 000 frames of ragged utterances (some shorter than every template, odd lengths) with variable template
+    lengths: tiles straddle utterances, workgroups end where the LDS image is full."""
+    from tsr_hip import synth
+    rng = np.random.default_rng(606)
+    T = rng.integers(1, 401, size=420)
+    T[rng.choice(420, size=12, replace=False)] = rng.integers(0, 20, size=12)
+    c = synth.corpus(606, N=420, T=T, F=45, E=8, M=8, L=[28, 29, 30, 32, 32, 33, 35, 36])
+    assert int(c["offsets"][-1]) >= 60000
+    _check(tsr_hip, oracle, c)
+
+
+def test_mx_long_utterance(tsr_hip, oracle):
+    from tsr_hip import synth
+    c = synth.corpus(70, N=2, T=[30001, 777], F=45, E=8, M=6, L=[32, 41, 36, 33, 40, 38])
+    _check(tsr_hip, oracle, c)
+
+
+def test_mx_requests_outside_its_envelope_are_served_as_fast(tsr_hip, oracle):
+    """More than eight templates, rows wider than 512 features, all-scores passes and short filters fall to TSR_FAST's
+    int8 kernels: same results as plain TSR_FAST, bit for bit."""
+    from tsr_hip import synth
+    for shape in (dict(N=3, T=[90, 140, 60], F=45, E=8, M=9, L=32), dict(N=2, T=[70, 90], F=80, E=8, M=4, L=32),
+                  dict(N=3, T=[40, 50, 30], F=6, E=5, M=3, L=9)):
+        c = synth.corpus(31, **shape)
+        P = int(c["offsets"][-1])
+        f2 = c["feats"].reshape(P, -1)
+        bank = tsr_hip.Bank(c["bank"])
+        s, a = bank.score(f2, c["offsets"], flags=tsr_hip.TSR_FAST | tsr_hip.TSR_MX)
+        sf, af = bank.score(f2, c["offsets"], flags=tsr_hip.TSR_FAST)
+        assert np.array_equal(s, sf) and np.array_equal(a, af)
+        bank.close()
+    c = synth.corpus(32, N=3, T=[90, 140, 60], F=45, E=8, M=8, L=32)
+    P = int(c["offsets"][-1])
+    bank = tsr_hip.Bank(c["bank"])
+    dc = tsr_hip.Corpus(c["feats"].reshape(P, -1), c["offsets"])
+    assert np.array_equal(dc.score_all(bank, tsr_hip.TSR_FAST | tsr_hip.TSR_MX), dc.score_all(bank, tsr_hip.TSR_FAST))
+    with pytest.raises(ValueError):
+        dc.score(bank, tsr_hip.TSR_FAST | tsr_hip.TSR_MX | tsr_hip.TSR_W24)
+    dc.close()
+    bank.close()
