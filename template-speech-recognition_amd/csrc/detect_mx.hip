@@ -57,7 +57,6 @@ struct MxCol {     // one of the 16 columns: (shift s = n >> 3, template m = n &
 struct MxArgs {
     const uint32_t *bits;     // [rows][DW] resident bit rows at virtual positions
     const unsigned char *B;   // [NKB][3 limbs][1536]: 64 lanes x 16 B, then 64 lanes x 8 B
-    const int32_t *koff;      // [NKB] LDS byte offset of the K-block's A fragments
     const MxGroup *groups;
     const int4 *wg;           // per workgroup: first tile, tiles, first virtual row, rows to stage
     const MxCol *cols;        // [16]
@@ -65,13 +64,26 @@ struct MxArgs {
     int32_t *ids;
     int n_groups, NKB, KBF, NR, Lmin, idmax;
     float cmax;
+    unsigned long long *dbg;  // -DTSR_STAMP builds only: [workgroup][wave][16] s_memtime stamps
 };
+
+// Development stamps (never in the shipped build): -DTSR_STAMP records s_memtime at the phase boundaries of every wave
+// and the launch dumps them to the file $TSR_STAMP_OUT (tools/mx_stamp_report.py).
+#ifdef TSR_STAMP
+#define MX_STAMP(i)                                                                            \
+    {                                                                                          \
+        unsigned long long t_;                                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+        if (lane == 0) a.dbg[((size_t)blockIdx.x * MX_WAVES + wave) * 16 + (i)] = t_;           \
+    }
+#else
+#define MX_STAMP(i)
+#endif
 
 struct MxBank {
     int KBF = 0, ROWS = 0, NKB = 0, NR = 0, Lmin = 0, Lmax = 0, idmax = 0;
     float cmax = 0;
     unsigned char *d_B = nullptr;
-    int32_t *d_koff = nullptr;
     MxCol *d_cols = nullptr;
 };
 
@@ -123,16 +135,64 @@ __global__ void mx_pack_bits_kernel(const uint8_t *feats, int Dp, const int64_t 
     bits[idx] = word;
 }
 
+constexpr int MX_STASH = 4096;                    // behind the LDS image: the workgroup's group records
+constexpr int MX_GROUPS = MX_NT * 16;             // 336 x 3 ints = 4032 bytes
+constexpr int MX_IMAGE = MX_LDS - MX_STASH;       // bytes the frame image may take
+#ifndef MX_ABL
+#define MX_ABL 0
+#endif
+constexpr int MX_DEPTH = 7;                       // A fragments in flight per wave
+static_assert(MX_NT % MX_DEPTH == 0 && MX_NT % 3 == 0, "the fragment ring must line up across K-blocks: tile j lives in A[j % MX_DEPTH]");
+
+template <int KBF>
 __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int CH = 4 * KBF, DW = 4 * KBF;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int4 wg = a.wg[blockIdx.x];
     const int tile_beg = wg.x, nt = wg.y, v_lo = wg.z, nfr = wg.w;
-    const int NR = a.NR, KBF = a.KBF, CH = 4 * KBF, DW = 4 * KBF;
+    const int NR = a.NR;
+    int *const g_row = reinterpret_cast<int *>(lds + MX_IMAGE);   // [336] LDS row of the group's first frame
+    int *const g_p0 = g_row + MX_GROUPS, *const g_rem = g_p0 + MX_GROUPS;
+    unsigned *const next_kb = reinterpret_cast<unsigned *>(g_rem + MX_GROUPS);   // the next K-block nobody has taken yet
 
-    // ---- B fragments of this wave's first K-block: in flight while the frames are staged ----
+    MX_STAMP(0)
+#ifdef TSR_STAMP
+    {
+        unsigned long long r_;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_)::"memory");
+        if (lane == 0) a.dbg[((size_t)blockIdx.x * MX_WAVES + wave) * 16 + 14] = r_;
+    }
+#endif
+    // ---- everything this workgroup reads from memory besides the bank is requested at once: the group records (one
+    //      per thread), the bit rows (five 16-byte pieces per thread), the first K-block's B fragments ----
+    const int n = lane & 15, s = n >> 3, rq = lane >> 4;
+    const MxCol col = a.cols[n];
+    MxGroup G = {v_lo, 0, 0, 0};
+    if (tid < MX_GROUPS) {
+        const int gi = tile_beg * 16 + tid;
+        if (tid < nt * 16 && gi < a.n_groups) G = a.groups[gi];
+    }
+    // frames -> LDS: lane = row of one (parity, K-block-of-the-row) pass, so that a wave's stores are consecutive 16-byte
+    // slots; at most 2 * KBF * NR <= 2496 pieces = five per thread
+    const int nrows = (nfr + 1) >> 1;
+    u32x4 piece[5];
+    int dst[5];
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+        const int idx = tid + it * (MX_WAVES * 64);
+        const int pass = idx / nrows, r = idx - pass * nrows;
+        const int plane = pass & 1, kbf = pass >> 1;
+        const int fr = 2 * r + plane;
+        piece[it] = u32x4{0, 0, 0, 0};
+        dst[it] = -1;
+        if (pass < 2 * KBF) {
+            dst[it] = ((plane * CH + 4 * kbf) * NR + r) << 4;
+            if (fr < nfr) piece[it] = *reinterpret_cast<const u32x4 *>(a.bits + (size_t)(v_lo + fr) * DW + 4 * kbf);
+        }
+    }
     const unsigned char *bp = a.B + (size_t)wave * (3 * 1536) + lane * 16;
     i32x4 b4[3];
     i32x2 b2[3];
@@ -141,66 +201,127 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
         b4[l] = *reinterpret_cast<const i32x4 *>(bp + l * 1536);
         b2[l] = *reinterpret_cast<const i32x2 *>(bp + l * 1536 + 1024 - lane * 8);
     }
-
-    // ---- frames -> LDS: bit rows expanded to fp4 nibbles (0x2 = 1.0), column-major; lane = row, so the stores of a
-    //      wave are consecutive 16-byte slots; element 8 k + j of a 32-feature chunk is feature 4 j + k (the bank's
-    //      fragments use the same order), which makes a chunk four shift-and-mask pairs ----
-    {
-        const int nrows = (nfr + 1) >> 1;
-        const int total = 2 * KBF * nrows;
-        for (int idx = tid; idx < total; idx += MX_WAVES * 64) {
-            const int pass = idx / nrows, r = idx - pass * nrows;
-            const int plane = pass & 1, kbf = pass >> 1;
-            const int fr = 2 * r + plane;
-            u32x4 b = {0, 0, 0, 0};
-            if (fr < nfr) b = *reinterpret_cast<const u32x4 *>(a.bits + (size_t)(v_lo + fr) * DW + 4 * kbf);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const unsigned x = b[q];
-                const u32x4 o = {(x << 1) & 0x22222222u, x & 0x22222222u, (x >> 1) & 0x22222222u, (x >> 2) & 0x22222222u};
-                *reinterpret_cast<u32x4 *>(lds + ((size_t)((plane * CH + 4 * kbf + q) * NR + r) << 4)) = o;
-            }
-        }
+    if (tid == 0) *next_kb = 2 * MX_WAVES;   // (wave w starts with the K-blocks w and w + 8)
+    if (tid < MX_GROUPS) {
+        g_row[tid] = (G.v0 - v_lo) >> 1;
+        g_p0[tid] = G.p0;
+        g_rem[tid] = G.rem;
     }
-
-    // per-lane LDS offset of (tile j, row lane & 15), the lane's K-quarter folded in
-    int tb[MX_NT];
+#ifdef TSR_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MX_STAMP(6)
+#endif
+    // bit rows expanded to fp4 nibbles (0x2 = 1.0): element 8 k + j of a 32-feature chunk is feature 4 j + k (the bank's
+    // fragments use the same order), which makes a chunk four shift-and-mask pairs
 #pragma unroll
-    for (int j = 0; j < MX_NT; ++j) {
-        const int gi = (tile_beg + j) * 16 + (lane & 15);
-        int v0 = v_lo;
-        if (j < nt && gi < a.n_groups) v0 = a.groups[gi].v0;
-        tb[j] = (((v0 - v_lo) >> 1) + NR * (lane >> 4)) << 4;
+    for (int it = 0; it < 5; ++it) {
+        if (dst[it] < 0) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned x = piece[it][q];
+            const u32x4 o = {(x << 1) & 0x22222222u, x & 0x22222222u, (x >> 1) & 0x22222222u, (x >> 2) & 0x22222222u};
+            *reinterpret_cast<u32x4 *>(lds + dst[it] + ((q * NR) << 4)) = o;
+        }
     }
     f32x4 acc[MX_NT];
 #pragma unroll
     for (int j = 0; j < MX_NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    MX_STAMP(1)
     __syncthreads();
+    MX_STAMP(2)
+    // per-lane LDS offset of (tile j, row lane & 15), the lane's K-quarter folded in
+    int tb[MX_NT];
+#pragma unroll
+    for (int j = 0; j < MX_NT; ++j) tb[j] = (g_row[j * 16 + (lane & 15)] + NR * (lane >> 4)) << 4;
+#ifdef MX_PRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 
-    // ---- K loop: this wave's K-blocks over all tiles ----
-    for (int kb = wave; kb < a.NKB; kb += MX_WAVES) {
-        const int koff = a.koff[kb];
+    // ---- K loop: K-blocks (a K-block = 128 features of one tap row) over all tiles; the A fragments of the next
+    //      MX_DEPTH tiles are in flight, across the K-block boundary too.  A wave draws its next K-block from a counter
+    //      in LDS while it works on this one: the two waves of a SIMD only fill the matrix pipe together (one wave alone
+    //      issues at half its rate, tools/ubench/mx_rate.hip), and with fixed shares the wave that loses the issue
+    //      arbitration is left to finish alone ----
+    auto koff_of = [&](int kb) {
+        const int rho = kb / KBF, kbf = kb - rho * KBF;
+        return ((rho >> 1) + NR * ((rho & 1) * CH + 4 * kbf)) << 4;
+    };
+    i32x4 A[MX_DEPTH];
+    int koff = koff_of(wave);
+#pragma unroll
+    for (int j = 0; j < MX_DEPTH; ++j) A[j] = *reinterpret_cast<const i32x4 *>(lds + tb[j] + koff);
+    // Two register sets for the B fragments, used alternately (the loop body exists twice so that no set is ever copied):
+    // one K-block's MFMAs read one set while the next K-block's fragments land in the other, requested piece by piece
+    // between the tile groups.  The draw of a K-block is one K-block ahead of that request, so that nobody waits for the
+    // atomic's return (a wave that waits issues nothing, and its SIMD partner alone runs at half rate).
+    int kb_1 = wave + MX_WAVES;   // the K-block after this one
+    auto kblock = [&](const i32x4 (&c4)[3], const i32x2 (&c2)[3], i32x4 (&n4)[3], i32x2 (&n2)[3]) -> bool {
+        // c: this K-block's fragments; n: the other set, which takes the next K-block's
+        int kb_2 = 0;
+        if (lane == 0) kb_2 = (int)__hip_atomic_fetch_add(next_kb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const bool more = kb_1 < a.NKB;
+        const int koff_n = more ? koff_of(kb_1) : koff;
+        const int kb_ld = more ? kb_1 : a.NKB - 1;
         i32x8 B[3];
 #pragma unroll
-        for (int l = 0; l < 3; ++l) B[l] = i32x8{b4[l][0], b4[l][1], b4[l][2], b4[l][3], b2[l][0], b2[l][1], 0, 0};
-        if (kb + MX_WAVES < a.NKB) {   // next K-block's fragments (used one iteration later)
-            const unsigned char *nb = a.B + (size_t)(kb + MX_WAVES) * (3 * 1536) + lane * 16;
+        for (int l = 0; l < 3; ++l) B[l] = i32x8{c4[l][0], c4[l][1], c4[l][2], c4[l][3], c2[l][0], c2[l][1], 0, 0};
+        // three tiles at a time, their limbs interleaved: a matrix instruction that adds to the accumulator of the one
+        // before it waits for its result (a lone wave then runs at half the pipe's rate); with two other tiles' between
+        // them the three accumulations of a tile are 48 cycles apart
 #pragma unroll
-            for (int l = 0; l < 3; ++l) {
-                b4[l] = *reinterpret_cast<const i32x4 *>(nb + l * 1536);
-                b2[l] = *reinterpret_cast<const i32x2 *>(nb + l * 1536 + 1024 - lane * 8);
+        for (int j = 0; j < MX_NT; j += 3) {
+            // one piece of the next K-block's fragments per tile group: a wave that issues its six loads
+            // back to back sits in that sequence for as long as the data takes (vector-memory instructions are issued at
+            // the rate the path delivers) and issues no matrix work meanwhile
+            // (unconditional -- behind the last K-block it re-reads that one -- so that the sets are plain registers, not
+            // merges of old and new values)
+            if (j / 3 < 6 && !(MX_ABL & 4)) {
+                const unsigned char *nb = a.B + (size_t)kb_ld * (3 * 1536) + lane * 16 + (j / 6) * 1536;
+                if ((j / 3) & 1) n2[j / 6] = *reinterpret_cast<const i32x2 *>(nb + 1024 - lane * 8);
+                else n4[j / 6] = *reinterpret_cast<const i32x4 *>(nb);
             }
-        }
+            i32x8 Af[3];
 #pragma unroll
-        for (int j = 0; j < MX_NT; ++j) {
-            const i32x4 x = *reinterpret_cast<const i32x4 *>(lds + tb[j] + koff);
-            const i32x8 A = {x[0], x[1], x[2], x[3], 0, 0, 0, 0};
-            acc[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B[0], acc[j], 4, 2, 0, 0x7f7f7f7f, 0, (int)0x82828282u);
-            acc[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B[1], acc[j], 4, 2, 0, 0x7f7f7f7f, 0, (int)0x86868686u);
-            acc[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B[2], acc[j], 4, 2, 0, 0x7f7f7f7f, 0, (int)0x8a8a8a8au);
+            for (int u = 0; u < 3; ++u) {
+                const i32x4 x = A[(j + u) % MX_DEPTH];
+                Af[u] = i32x8{x[0], x[1], x[2], x[3], 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                acc[j + u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(Af[u], B[0], acc[j + u], 4, 2, 0, 0x7f7f7f7f, 0, (int)0x82828282u);
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                acc[j + u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(Af[u], B[1], acc[j + u], 4, 2, 0, 0x7f7f7f7f, 0, (int)0x86868686u);
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                acc[j + u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(Af[u], B[2], acc[j + u], 4, 2, 0, 0x7f7f7f7f, 0, (int)0x8a8a8a8au);
+            // (behind the group's matrix instructions, which read the ring slots these reads refill: no copies of the slots)
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int jn = j + u + MX_DEPTH;
+#if MX_ABL & 1   // development ablation: no fragment reads inside the loop (wrong sums)
+                (void)jn;
+#elif MX_ABL & 2   // development ablation: no address arithmetic per read (wrong sums)
+                A[(j + u) % MX_DEPTH] = *reinterpret_cast<const i32x4 *>(lds + (jn < MX_NT ? tb[jn] : tb[jn - MX_NT]));
+#else
+                A[(j + u) % MX_DEPTH] = *reinterpret_cast<const i32x4 *>(lds + (jn < MX_NT ? tb[jn] + koff : tb[jn - MX_NT] + koff_n));
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);   // (the compiler otherwise sinks the reads to just in front of their use)
         }
+        koff = koff_n;
+        kb_1 = __builtin_amdgcn_readfirstlane(kb_2);
+        return more;
+    };
+    i32x4 d4[3] = {b4[0], b4[1], b4[2]};
+    i32x2 d2[3] = {b2[0], b2[1], b2[2]};
+    while (kblock(b4, b2, d4, d2) && kblock(d4, d2, b4, b2)) {
     }
+#ifdef MX_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 
+    MX_STAMP(3)
     // ---- the eight partial sums of a tile meet in LDS (the frames are done with): tile j belongs to wave j & 7 ----
     __syncthreads();
 #pragma unroll
@@ -212,39 +333,116 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
         }
     }
     __syncthreads();
-    const int n = lane & 15, s = n >> 3, rq = lane >> 4;
-    const MxCol col = a.cols[n];
+    MX_STAMP(4)
+    // the wave's own partial sums of its (at most three) tiles, picked by wave-uniform branches so that the finishing code
+    // below exists three times instead of once per tile (it runs once per wave: every copy is a cold instruction fetch)
+    f32x4 own[3] = {acc[0], acc[8], acc[16]};
 #pragma unroll
-    for (int j = 0; j < MX_NT; ++j) {
-        if ((j & 7) != wave || j >= nt) continue;
-        f32x4 sum = acc[j];
+    for (int w = 1; w < MX_WAVES; ++w) {
+        if (wave == w) {
+            own[0] = acc[w];
+            own[1] = acc[w + 8];
+            if (w + 16 < MX_NT) own[2] = acc[w + 16];
+        }
+    }
+    // The wave's (at most three) tiles are finished together, stage by stage: every stage is a round trip to LDS, and a
+    // tile's result write may alias the next tile's reads as far as the compiler can tell, so tile after tile would be
+    // nine dependent round trips instead of three.
+    int jj[3];
+    bool ok[3];
 #pragma unroll
-        for (int r = 0; r < 7; ++r) sum += *reinterpret_cast<const f32x4 *>(lds + ((size_t)(j * 7 + r) << 10) + lane * 16);
+    for (int u = 0; u < 3; ++u) {
+        jj[u] = wave + 8 * u;
+        ok[u] = jj[u] < nt && jj[u] < MX_NT;
+        if (!ok[u]) jj[u] = 0;   // (reads of tile 0's slots are harmless; nothing is written or stored for it)
+    }
+    MX_STAMP(7)
+    f32x4 sum[3] = {own[0], own[1], own[2]};
+    i32x4 RM[3];
+    int fp0[3], frem[3], tp0[3], trem[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        RM[u] = *reinterpret_cast<const i32x4 *>(g_rem + jj[u] * 16 + 4 * rq);   // frames left, the lane's four rows
+        fp0[u] = g_p0[jj[u] * 16 + ((lane >> 1) & 15)];                         // lane < 32: the frame lane of the tile
+        frem[u] = g_rem[jj[u] * 16 + ((lane >> 1) & 15)];
+        tp0[u] = g_p0[jj[u] * 16 + (lane & 15)];                                // lane < 16: row lane of the tile
+        trem[u] = g_rem[jj[u] * 16 + (lane & 15)];
+    }
+#pragma unroll
+    for (int r = 0; r < 7; ++r)   // (reads only: the compiler keeps as many in flight as it has registers for)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) sum[u] += *reinterpret_cast<const f32x4 *>(lds + ((size_t)(jj[u] * 7 + r) << 10) + lane * 16);
+    unsigned best[3][4];
+    int first[3][4];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int gi = (tile_beg + j) * 16 + 4 * rq + g;
-            MxGroup G = {0, 0, 0, 0};
-            if (gi < a.n_groups) G = a.groups[gi];
-            const bool valid = s + col.L <= G.rem;   // the window of template m at t0 + s lies inside the utterance
-            const float val = (valid ? sum[g] * col.inv_scale : 0.0f) + col.c;   // (tail rule: 0 + c_m)
-            unsigned long long key = ((unsigned long long)orderable(val) << 32) | (unsigned)~col.id;
+            const bool valid = s + col.L <= RM[u][g];   // the window of template m at t0 + s lies inside the utterance
+            const float val = (valid ? sum[u][g] * col.inv_scale : 0.0f) + col.c;   // (tail rule: 0 + c_m)
+            // max over the eight templates of this shift (lanes 8 s .. 8 s + 7), the lowest id among the maxima: three DPP
+            // exchanges on the orderable score, then the first lane of the eight that holds the maximum
+            const unsigned ov = orderable(val);
+            unsigned b = ov;
+            b = max(b, (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+            b = max(b, (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+            b = max(b, (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x141, 0xf, 0xf, false));   // row_half_mirror
+            const unsigned long long hit = __ballot(ov == b);
+            best[u][g] = b;
+            first[u][g] = __builtin_ctz((unsigned)(hit >> (lane & 56)) & 0xffu);   // (template ids are the lane order)
+        }
+    }
+    // a tile's 32 results (rows x shifts) go through LDS -- the tile's own slots, read above and free now -- so that they
+    // leave as two coalesced stores instead of eight scattered ones
 #pragma unroll
-            for (int x = 1; x < 8; x <<= 1) {   // max over the eight templates of this shift: highest score, lowest id on ties
-                const unsigned long long o = __shfl_xor(key, x);
-                key = o > key ? o : key;
-            }
-            if ((n & 7) == 0 && s < G.rem) {
-                a.scores[G.p0 + s] = unorderable((unsigned)(key >> 32));
-                a.ids[G.p0 + s] = (int)~(unsigned)key;
-            }
-            if (G.rem > 2 && G.rem < a.Lmin + 2) {   // last group of its utterance: the frames behind it score max_m c_m
-                for (int t = 2 + n; t < G.rem; t += 16) {
-                    a.scores[G.p0 + t] = a.cmax;
-                    a.ids[G.p0 + t] = a.idmax;
-                }
+    for (int u = 0; u < 3; ++u) {
+        unsigned *const res = reinterpret_cast<unsigned *>(lds + ((size_t)(jj[u] * 7) << 10));
+        if ((n & 7) == 0 && ok[u]) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                res[2 * (4 * rq + g) + s] = best[u][g];
+                res[32 + 2 * (4 * rq + g) + s] = (unsigned)first[u][g];
             }
         }
     }
+    unsigned sc[3], id[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {   // (same wave: LDS operations execute in order)
+        const unsigned *const res = reinterpret_cast<const unsigned *>(lds + ((size_t)(jj[u] * 7) << 10));
+        sc[u] = res[lane & 31];
+        id[u] = res[32 + (lane & 31)];
+    }
+    MX_STAMP(8)
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        if (ok[u] && lane < 32 && (lane & 1) < frem[u]) {
+            a.scores[fp0[u] + (lane & 1)] = unorderable(sc[u]);
+            a.ids[fp0[u] + (lane & 1)] = (int)id[u];
+        }
+    }
+    // the last group of an utterance: the frames behind its two starts score max_m c_m (every template is in its tail
+    // there).  Rows are flagged by lanes 0..15, the whole wave then fills one flagged row after the other.
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        unsigned long long todo = __ballot(ok[u] && lane < 16 && trem[u] > 2 && trem[u] < a.Lmin + 2);
+        while (todo) {
+            const int i = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int bp = __builtin_amdgcn_readlane(tp0[u], i), br = __builtin_amdgcn_readlane(trem[u], i);
+            for (int t = 2 + lane; t < br; t += 64) {
+                a.scores[bp + t] = a.cmax;
+                a.ids[bp + t] = a.idmax;
+            }
+        }
+    }
+    MX_STAMP(5)
+#ifdef TSR_STAMP
+    {
+        unsigned long long r_;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_)::"memory");
+        if (lane == 0) a.dbg[((size_t)blockIdx.x * MX_WAVES + wave) * 16 + 15] = r_;
+    }
+#endif
 }
 
 inline MxBank *mxb(const tsr_bank *b) { return static_cast<MxBank *>(b->mx); }
@@ -265,7 +463,6 @@ void tsr_mx_bank_free(tsr_bank *bank)
     (void)hipSetDevice(bank->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(mb->d_B);
-    (void)hipFree(mb->d_koff);
     (void)hipFree(mb->d_cols);
     delete mb;
     bank->mx = nullptr;
@@ -299,7 +496,7 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
     int Lmin = bank->L[0];
     for (int m = 0; m < M; ++m) Lmin = std::min(Lmin, bank->L[m]);
     const int ROWS = bank->Lmax + 1, NKB = ROWS * KBF;
-    const int NR = MX_LDS / (128 * KBF) / 16 * 16;   // rows per column array: a multiple of 16 (conflict-free fragment reads)
+    const int NR = MX_IMAGE / (128 * KBF) / 16 * 16;   // rows per column array: a multiple of 16 (conflict-free fragment reads)
     if (ROWS + 34 > 2 * NR) {   // (a tile of one long utterance spans 32 + ROWS frames)
         bank->mx_unsupported = true;
         return TSR_ERR_UNSUPPORTED;
@@ -327,11 +524,8 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
         else cols[n] = MxCol{0.0f, -INFINITY, 1 << 30, 0x7ffffffe};
     }
     std::vector<unsigned char> Bf((size_t)NKB * 3 * 1536, 0);
-    std::vector<int32_t> koff(NKB);
-    const int CH = 4 * KBF;
     for (int kb = 0; kb < NKB; ++kb) {
         const int rho = kb / KBF, kbf = kb % KBF;
-        koff[kb] = ((rho >> 1) + NR * ((rho & 1) * CH + 4 * kbf)) << 4;
         for (int lane = 0; lane < 64; ++lane) {
             const int n = lane & 15, q = lane >> 4, s = n >> 3, m = n & 7;
             uint32_t str[3][6] = {{0}};
@@ -368,7 +562,6 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
         if (hipMalloc(d, bytes) != hipSuccess || hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = TSR_ERR_HIP;
     };
     up(reinterpret_cast<void **>(&mb->d_B), Bf.data(), Bf.size());
-    up(reinterpret_cast<void **>(&mb->d_koff), koff.data(), koff.size() * 4);
     up(reinterpret_cast<void **>(&mb->d_cols), cols.data(), cols.size() * sizeof(MxCol));
     if (st == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = TSR_ERR_HIP;
     bank->mx = mb;
@@ -506,18 +699,43 @@ int tsr_launch_mx_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, float
     TSR_TRY(mx_corpus_plan(ctx, cp, mb));
     const MxCorpus *mc = mxc(cp);
     if (mc->n_wg == 0) return TSR_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        TSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mx_bank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS));
-        attr_set = true;
+    const void *kern = mb->KBF == 1 ? reinterpret_cast<const void *>(mx_bank_kernel<1>) : mb->KBF == 2 ? reinterpret_cast<const void *>(mx_bank_kernel<2>)
+                     : mb->KBF == 3 ? reinterpret_cast<const void *>(mx_bank_kernel<3>) : reinterpret_cast<const void *>(mx_bank_kernel<4>);
+    static bool attr_set[MX_MAX_KBF + 1] = {false, false, false, false, false};
+    if (!attr_set[mb->KBF]) {
+        TSR_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS));
+        attr_set[mb->KBF] = true;
     }
     MxArgs a;
-    a.bits = mc->d_bits; a.B = mb->d_B; a.koff = mb->d_koff; a.groups = mc->d_groups; a.wg = mc->d_wg; a.cols = mb->d_cols;
+    a.bits = mc->d_bits; a.B = mb->d_B; a.groups = mc->d_groups; a.wg = mc->d_wg; a.cols = mb->d_cols;
     a.scores = d_scores; a.ids = d_ids;
     a.n_groups = mc->n_groups; a.NKB = mb->NKB; a.KBF = mb->KBF; a.NR = mb->NR; a.Lmin = mb->Lmin; a.idmax = mb->idmax; a.cmax = mb->cmax;
-    const size_t lds = std::max<size_t>((size_t)128 * mb->KBF * mb->NR, (size_t)MX_NT * 7 * 1024);
-    TSR_REQUIRE(lds <= (size_t)MX_LDS, "TSR_MX: LDS image of %zu bytes", lds);
-    hipLaunchKernelGGL(mx_bank_kernel, dim3((unsigned)mc->n_wg), dim3(MX_WAVES * 64), lds, ctx->stream, a);
-    TSR_HIP(hipGetLastError());
+    TSR_REQUIRE((size_t)128 * mb->KBF * mb->NR <= (size_t)MX_IMAGE && (size_t)MX_NT * 7 * 1024 <= (size_t)MX_IMAGE, "TSR_MX: LDS image too large");
+    const size_t lds = MX_LDS;
+    a.dbg = nullptr;
+#ifdef TSR_STAMP
+    const size_t nst = (size_t)mc->n_wg * MX_WAVES * 16;
+    TSR_HIP(hipMalloc(reinterpret_cast<void **>(&a.dbg), nst * 8));
+    TSR_HIP(hipMemsetAsync(a.dbg, 0, nst * 8, ctx->stream));
+#endif
+    void *kargs[] = {&a};
+    TSR_HIP(hipLaunchKernel(kern, dim3((unsigned)mc->n_wg), dim3(MX_WAVES * 64), kargs, lds, ctx->stream));
+#ifdef TSR_STAMP
+    if (const char *path = getenv("TSR_STAMP_OUT")) {
+        std::vector<unsigned long long> h(nst);
+        TSR_HIP(hipMemcpyAsync(h.data(), a.dbg, nst * 8, hipMemcpyDeviceToHost, ctx->stream));
+        TSR_HIP(hipStreamSynchronize(ctx->stream));
+        if (FILE *f = fopen(path, "w")) {
+            for (size_t i = 0; i < nst / 16; ++i) {
+                fprintf(f, "%zu %zu", i / MX_WAVES, i % MX_WAVES);
+                for (int k = 0; k < 16; ++k) fprintf(f, " %llu", h[i * 16 + k]);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+    }
+    TSR_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(a.dbg);
+#endif
     return TSR_OK;
 }

@@ -8,7 +8,7 @@ pids=()
 for f in csrc/*.hip; do
     o=lib/obj_stamp/$(basename "$f").o
     case "$f" in
-    *detect_mfma*) /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -fvisibility=hidden -DTSR_STAMP -c "$f" -o "$o" & pids+=($!) ;;
+    *detect_mfma*|*detect_mx*) /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -fvisibility=hidden -DTSR_STAMP -c "$f" -o "$o" & pids+=($!) ;;
     *) [ "$o" -nt "$f" ] || { /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -fvisibility=hidden -c "$f" -o "$o" & pids+=($!); } ;;
     esac
 done

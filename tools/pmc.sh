@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out && export TMPDIR=/tmp
 TAG=${2:-pmc}
 rm -rf gpurun_out/$TAG
-timeout -k 10 300 rocprofv3 --pmc $1 --kernel-trace --output-format csv -d gpurun_out/$TAG -o $TAG -- python3 tools/time_fast.py > gpurun_out/$TAG.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc $1 --kernel-trace --output-format csv -d gpurun_out/$TAG -o $TAG -- python3 tools/time_fast.py ${3:-} > gpurun_out/$TAG.log 2>&1
 echo "rc=$?"; tail -1 gpurun_out/$TAG.log
 python3 - <<PY
 import csv, glob, collections

@@ -1,0 +1,146 @@
+// Issue rate of v_mfma_scale_f32_16x16x128_f8f6f4 (fp4 x fp6) per wave and per SIMD on gfx950:
+//   W waves per SIMD (1..4), scale operands as block scales (S = 1) or the constant 0 (S = 0: does the compiler pick the
+//   unscaled encoding, and is that one faster?), accumulations dependent in threes (D = 1) or spread over 9 accumulators (D = 0).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+using i32x8 = __attribute__((ext_vector_type(8))) int;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+template <int W, int S, int D>
+__global__ __launch_bounds__(W * 256, W) void rate(int steps, unsigned long long *out, float *sink, const i32x8 *ain, const i32x8 *bin)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    i32x8 A = ain[lane], B0 = bin[lane], B1 = bin[64 + lane], B2 = bin[128 + lane];
+    f32x4 acc[9] = {};
+    unsigned long long t0, r0, t1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
+    for (int s = 0; s < steps; ++s) {
+        if (D) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                acc[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B0, acc[j], 4, 2, 0, S ? 0x7f7f7f7f : 0, 0, S ? (int)0x82828282u : 0);
+                acc[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B1, acc[j], 4, 2, 0, S ? 0x7f7f7f7f : 0, 0, S ? (int)0x86868686u : 0);
+                acc[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B2, acc[j], 4, 2, 0, S ? 0x7f7f7f7f : 0, 0, S ? (int)0x8a8a8a8au : 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 9; ++j)
+                acc[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, j % 3 == 0 ? B0 : j % 3 == 1 ? B1 : B2, acc[j], 4, 2, 0, S ? 0x7f7f7f7f : 0, 0,
+                                                                          S ? (int)0x82828282u : 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
+    float x = 0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) x += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    if (x == 1.2345f) sink[0] = x;
+    if (lane == 0) {
+        out[(blockIdx.x * 16 + wave) * 2] = t1 - t0;
+        out[(blockIdx.x * 16 + wave) * 2 + 1] = r1 - r0;
+    }
+}
+
+// the K loop of csrc/detect_mx.hip without its memory traffic: NT accumulators, three tiles x three limbs interleaved, the A
+// operand from a ring of seven register sets, two B sets alternating per K-block
+template <int W, int NT>
+__global__ __launch_bounds__(W * 256, W) void loop_like(int steps, unsigned long long *out, float *sink, const i32x8 *ain, const i32x8 *bin)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    i32x8 A[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { A[i] = ain[(lane + i) & 63]; A[i][4] = A[i][5] = A[i][6] = A[i][7] = 0; }
+    i32x8 B[3] = {bin[lane], bin[64 + lane], bin[128 + lane]};
+    f32x4 acc[NT] = {};
+    unsigned long long t0, r0, t1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
+    for (int s = 0; s < steps; ++s) {
+#pragma unroll
+        for (int j = 0; j < NT; j += 3) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                acc[j + u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A[(j + u) % 7], B[0], acc[j + u], 4, 2, 0, 0x7f7f7f7f, 0, (int)0x82828282u);
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                acc[j + u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A[(j + u) % 7], B[1], acc[j + u], 4, 2, 0, 0x7f7f7f7f, 0, (int)0x86868686u);
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                acc[j + u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A[(j + u) % 7], B[2], acc[j + u], 4, 2, 0, 0x7f7f7f7f, 0, (int)0x8a8a8a8au);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
+    float x = 0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) x += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    if (x == 1.2345f) sink[0] = x;
+    if (lane == 0) {
+        out[(blockIdx.x * 16 + wave) * 2] = t1 - t0;
+        out[(blockIdx.x * 16 + wave) * 2 + 1] = r1 - r0;
+    }
+}
+
+template <int W, int NT> int run_like(unsigned long long *dout, float *dsink, const i32x8 *da, const i32x8 *db)
+{
+    const int steps = 400;
+    CK(hipMemset(dout, 0, 256 * 16 * 16));
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((loop_like<W, NT>), dim3(256), dim3(W * 256), 0, 0, steps, dout, dsink, da, db);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h(256 * 16 * 2);
+    CK(hipMemcpy(h.data(), dout, h.size() * 8, hipMemcpyDeviceToHost));
+    double cyc = 0, real = 0;
+    int n = 0;
+    for (int i = 0; i < 256 * 16; ++i)
+        if (h[2 * i]) { cyc += h[2 * i]; real += h[2 * i + 1]; ++n; }
+    const double per = cyc / n / (steps * 3.0 * NT);
+    printf("%d wave(s) per SIMD, loop-like, %d accumulators: %.2f cycles per instruction per wave = %.2f per SIMD, clock %.3f GHz\n", W, NT, per, per / W,
+           cyc / real / 10.0);
+    return 0;
+}
+
+template <int W, int S, int D> int run(unsigned long long *dout, float *dsink, const i32x8 *da, const i32x8 *db)
+{
+    const int steps = 2000;
+    CK(hipMemset(dout, 0, 256 * 16 * 16));
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((rate<W, S, D>), dim3(256), dim3(W * 256), 0, 0, steps, dout, dsink, da, db);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h(256 * 16 * 2);
+    CK(hipMemcpy(h.data(), dout, h.size() * 8, hipMemcpyDeviceToHost));
+    double cyc = 0, real = 0;
+    int n = 0;
+    for (int i = 0; i < 256 * 16; ++i)
+        if (h[2 * i]) { cyc += h[2 * i]; real += h[2 * i + 1]; ++n; }
+    const double per = cyc / n / (steps * 9.0);
+    printf("%d wave(s) per SIMD, %s, %s: %.2f cycles per instruction per wave = %.2f per SIMD, clock %.3f GHz\n", W, S ? "block scales" : "scale operands 0",
+           D ? "dependent in threes" : "9 accumulators", per, per / W, cyc / real / 10.0);
+    return 0;
+}
+
+int main()
+{
+    std::vector<unsigned> a(64 * 8), b(192 * 8);
+    unsigned st = 12345;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return st >> 8; };
+    for (auto &v : a) v = rnd() & 0x22222222u & (rnd() << 8);
+    for (size_t i = 0; i < b.size(); ++i) b[i] = (i % 8) < 6 ? ((rnd() << 8) ^ rnd()) & 0x9e79e79eu : 0;   // small digits
+    unsigned *da, *db;
+    unsigned long long *dout;
+    float *dsink;
+    CK(hipMalloc(&da, a.size() * 4)); CK(hipMalloc(&db, b.size() * 4)); CK(hipMalloc(&dout, 256 * 16 * 16)); CK(hipMalloc(&dsink, 16));
+    CK(hipMemcpy(da, a.data(), a.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(db, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+    run<1, 1, 0>(dout, dsink, (i32x8 *)da, (i32x8 *)db);
+    run<1, 1, 1>(dout, dsink, (i32x8 *)da, (i32x8 *)db);
+    run<1, 0, 0>(dout, dsink, (i32x8 *)da, (i32x8 *)db);
+    run<2, 1, 0>(dout, dsink, (i32x8 *)da, (i32x8 *)db);
+    run<2, 1, 1>(dout, dsink, (i32x8 *)da, (i32x8 *)db);
+    run<2, 0, 0>(dout, dsink, (i32x8 *)da, (i32x8 *)db);
+    run_like<2, 9>(dout, dsink, (i32x8 *)da, (i32x8 *)db);
+    run_like<2, 21>(dout, dsink, (i32x8 *)da, (i32x8 *)db);
+    run_like<1, 21>(dout, dsink, (i32x8 *)da, (i32x8 *)db);
+    run<3, 1, 0>(dout, dsink, (i32x8 *)da, (i32x8 *)db);
+    run<4, 1, 0>(dout, dsink, (i32x8 *)da, (i32x8 *)db);
+    return 0;
+}
