@@ -128,11 +128,16 @@ CFG = dict(N=1000, T=200, F=45, E=8, M=8, L=32)
 D = CFG["F"] * CFG["E"]
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 MFMA_I8_PEAK_TOPS = 5000.0    # dense int8 MFMA = 2x bf16 (~2.5 PF) per clock
+MFMA_FP6_PEAK_TOPS = 10000.0  # dense fp6 / fp4 MFMA (block-scaled forms) = 4x bf16 per clock (MI355X_MICROARCH.md)
 VALU_F32_PEAK_TFLOPS = 157.3
 L3_BYTES = 256 << 20
 ALG_BYTES_PER_FRAME = D + 6   # D u8 in + f32 max + 2-byte id
-FLAGS = {"fast": tsr_hip.TSR_FAST, "fast24": tsr_hip.TSR_FAST | tsr_hip.TSR_W24, "exact": tsr_hip.TSR_EXACT}
-DTYPE = {"fast": "i8 (2 limbs, i32 accumulate)", "fast24": "i8 (3 limbs, i32 accumulate)", "exact": "f32"}
+FLAGS = {"mx": tsr_hip.TSR_FAST | tsr_hip.TSR_MX, "fast": tsr_hip.TSR_FAST, "fast24": tsr_hip.TSR_FAST | tsr_hip.TSR_W24,
+         "exact": tsr_hip.TSR_EXACT}
+DTYPE = {"mx": "fp6 x fp4 (13-bit weights as 3 fp6 digits, binary frames as fp4; exact integer sums in one f32 accumulator)",
+         "fast": "i8 (2 limbs, i32 accumulate)", "fast24": "i8 (3 limbs, i32 accumulate)", "exact": "f32"}
+KERNEL_NAMES = {0: "none", 1: "exact_bank_kernel", 2: "exact_mfma_kernel", 3: "fast_bank_kernel / alt_bank_kernel", 4: "tap2_bank_kernel",
+                5: "mx_bank_kernel"}
 ALG_FLOPS = 2.0 * D * CFG["M"] * CFG["L"] * (CFG["T"] - CFG["L"] + 1) * CFG["N"]   # per launch (valid windows)
 
 
@@ -308,6 +313,7 @@ def long_corpus(ctx, corpus, bank, flags, times=10):
     return {"utterances_per_launch": (len(offs) - 1), "frames_per_launch": frames, "kernel_ms_per_launch": ms,
             "kernel_us_per_1000_utterances": ms * 1e3 / times, "frames_per_s": frames / (ms * 1e-3),
             "alg_tflops": ALG_FLOPS * times / (ms * 1e-3) / 1e12, "frac_of_int8_peak": ALG_FLOPS * times / (ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
+            "frac_of_hbm_peak": ALG_BYTES_PER_FRAME * frames / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "hbm_gbs_alg": ALG_BYTES_PER_FRAME * frames / (ms * 1e-3) / 1e9, "first_and_last_copy_score_alike": same,
             "what": "config 2's corpus %d times over in one launch: prologue and launch amortised %dx" % (times, times)}
 
@@ -354,9 +360,29 @@ def roofline_of(mode, per_launch_s, frames, traffic):
         # roofline is what the contract asks to be reported against
         return dict(hbm, bound="hbm", traffic=traffic, kernel_ms_per_launch=per_launch_s * 1e3,
                     valu_tflops=ALG_FLOPS / per_launch_s / 1e12, valu_peak_tflops=VALU_F32_PEAK_TFLOPS)
+    tops = ALG_FLOPS / per_launch_s / 1e12
+    if mode == "mx":
+        # fp6 x fp4 at ~10 PF: machine balance 1250 op/B against the path's 425 flop/B -- by algorithmic work HBM binds
+        # (73.2 MB at 8 TB/s = 9.2 us against 31.15 Gflop at 10 PF = 3.1 us).  What the kernel issues is three digit
+        # products per algorithmic MAC on 33 tap rows x 384 features for windows of 32 x 360 (x 170/169 start pairs):
+        # 9.9 us of matrix work at the spec peak -- the two bounds are level, and both are reported.
+        limbs, kpad, rows = 3, (128 * math.ceil(D / 128)) / D, (CFG["L"] + 1) / CFG["L"]
+        pairs = 2 * math.ceil((CFG["T"] - CFG["L"] + 1) / 2) / (CFG["T"] - CFG["L"] + 1)
+        issued = tops * limbs * kpad * rows * pairs
+        return dict(hbm, bound="hbm", traffic=traffic, kernel_ms_per_launch=per_launch_s * 1e3, alg_flops_per_launch=ALG_FLOPS,
+                    mfma={"achieved": tops, "peak": MFMA_FP6_PEAK_TOPS, "unit": "TFLOP/s", "frac": tops / MFMA_FP6_PEAK_TOPS,
+                          "issued": {"digit_macs_per_alg_mac": limbs, "k_pad": kpad, "tap_rows": rows, "start_pairs": pairs,
+                                     "fp6_tops": issued, "frac_of_peak": issued / MFMA_FP6_PEAK_TOPS, "kernel": "mx_bank_kernel",
+                                     "what": "fp6 x fp4 ops the kernel issues = algorithmic x 3 digits x K padding (%d/%d) x tap rows "
+                                             "(%d/%d) x start pairs" % (128 * math.ceil(D / 128), D, CFG["L"] + 1, CFG["L"])},
+                          "peak_note": "dense fp6 / fp4 MFMA = 4x the ~2.5 PF bf16 dense peak (MI355X_MICROARCH.md)"},
+                    bound_note="algorithmic intensity 425 flop/B is below the fp6 machine balance of 1250 op/B: HBM is the "
+                               "binding roofline of this path at this precision; `achieved` = algorithmic bytes (366 B per "
+                               "frame: D u8 in + score + id out) per launch / kernel time.  The kernel itself reads the "
+                               "corpus' resident bit rows (48 B per frame), so its measured traffic is BELOW the algorithmic "
+                               "bytes.  The matrix-core view of the same launch is under `mfma`.")
     # 425 flop/B at M=8 vs a machine balance of ~600 int8-op/B -- close to the
     # ridge, and each algorithmic MAC costs 2 (3) int8 limb-MACs, so the matrix cores bind
-    tops = ALG_FLOPS / per_launch_s / 1e12
     limbs = 2 if mode == "fast" else 3
     # which two-limb kernel tsr_corpus_score picks (tsr_api.hip): the tap-pair kernel when the resident rows are an
     # odd number (<= 23) of 16-byte slots
@@ -387,7 +413,7 @@ def roofline_of(mode, per_launch_s, frames, traffic):
 def stored_traffic(mode):
     """HBM bytes per launch from the PMC passes committed under profiles/ (collected by tools/traffic.sh on
     the > L3 working set, gfx950 corrections applied) -- NOT measured in this run."""
-    for name in ("r03_traffic_%s.json" % mode, "r02_traffic_%s.json" % mode, "traffic_%s.json" % mode):  # newest round first
+    for name in ("r04_traffic_%s.json" % mode, "r03_traffic_%s.json" % mode, "r02_traffic_%s.json" % mode, "traffic_%s.json" % mode):  # newest round first
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             j = json.load(open(p))
@@ -422,10 +448,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", choices=["auto", "fast", "fast24", "exact"],
+    ap.add_argument("--mode", choices=["auto", "mx", "fast", "fast24", "exact"],
                     default=os.environ.get("TSR_BENCH_MODE", "auto"),
-                    help="fast: MFMA, 16-bit fixed-point weights (2 int8 limbs); fast24: 23-bit "
-                         "(3 limbs); exact: f32 VALU in the reference's summation order")
+                    help="mx: 13-bit weights as three fp6 digits on the block-scaled matrix instruction (Toeplitz form); "
+                         "fast: 16-bit fixed-point weights (2 int8 limbs); fast24: 23-bit (3 limbs); exact: f32 in the "
+                         "reference's summation order; auto: the fastest of these that passes the in-run parity check")
     ap.add_argument("--replicas", type=int, default=0,
                     help="device-resident copies of the corpus per step (0: enough for >= 5 ms per step "
                          "and a working set of >= 4x the Infinity Cache)")
@@ -505,11 +532,11 @@ def main():
         bank = tsr_hip.Bank(corpus["bank"], ctx=ctx)
     frames = int(corpus["offsets"][-1])
     first = tsr_hip.Corpus(corpus["feats"], corpus["offsets"], ctx=ctx)
-    if args.mode == "auto":  # the MFMA path when this build has it, else the exact VALU path
+    if args.mode == "auto":  # the fastest path this build has for the bank: mx where its kernel serves it, else fast, else exact
         try:
-            first.score(bank, tsr_hip.TSR_FAST)
+            first.score(bank, FLAGS["mx"])
             ctx.sync()
-            args.mode = "fast"
+            args.mode = "mx" if ctx.get_option(tsr_hip.TSR_INFO_LAST_BANK_KERNEL) == tsr_hip.TSR_KERNEL_MX else "fast"
         except tsr_hip.TsrError as e:
             if e.status != 4:
                 raise
@@ -524,8 +551,10 @@ def main():
     def n_replicas(ms_per_launch):
         if args.replicas > 0:
             return args.replicas
-        r = max(int(math.ceil(5.0 / ms_per_launch)), int(math.ceil(4.0 * L3_BYTES / (frames * (D + 8 + 12)))))
-        return min(r, 192)     # <= 15 GB of HBM
+        # bytes a launch streams per frame: the resident byte rows + tables + results, or (mx) the bit rows + results
+        per_frame = (16 * math.ceil(D / 128) + 8 + 4) if args.mode == "mx" else (D + 8 + 12)
+        r = max(int(math.ceil(5.0 / ms_per_launch)), int(math.ceil(4.0 * L3_BYTES / (frames * per_frame))))
+        return min(r, 192)     # <= 16 GB of HBM
 
     R = int(tdist.max_over_ranks(group, float(n_replicas(resident_ms)))[0])
     replicas = [first] + [tsr_hip.Corpus(corpus["feats"], corpus["offsets"], ctx=ctx) for _ in range(R - 1)]
@@ -575,15 +604,18 @@ def main():
             "config": {"workload": "config 2: %d utterances x %d frames x D=%d binary features, %d-template bank, "
                                    "L=%d, max-score + template id per frame = one launch; one step = %d launches "
                                    "over %d device-resident copies of the corpus (%.0f MB working set per GPU, "
-                                   "streamed from HBM)"
-                                   % (CFG["N"], CFG["T"], D, CFG["M"], CFG["L"], R, R, R * frames * (D + 20) / 1e6),
+                                   "streamed from HBM%s)"
+                                   % (CFG["N"], CFG["T"], D, CFG["M"], CFG["L"], R, R, R * frames * (D + 20) / 1e6,
+                                      "; the mx kernel reads each copy's bit rows, %.0f MB of them" % (R * frames * 16 * math.ceil(D / 128) / 1e6)
+                                      if args.mode == "mx" else ""),
                        "mode": args.mode, "frames_per_launch": frames, "launches_per_step": R,
                        "frames_per_gpu_per_step": frames * R, "parallelism": "utterance-sharded x%d" % world,
-                       "bank_broadcast": bank_bcast, "parity_rel_err_sample": err},
+                       "bank_broadcast": bank_bcast, "parity_rel_err_sample": err,
+                       "kernel": KERNEL_NAMES.get(ctx.get_option(tsr_hip.TSR_INFO_LAST_BANK_KERNEL), "?")},
             "roofline": roofline,
             "cache_resident": {"kernel_ms_per_launch": resident_ms, "frames_per_s": frames / (resident_ms * 1e-3),
-                               "what": "the same launch on ONE corpus over and over (73.6 MB, served from the "
-                                       "256 MiB Infinity Cache): round 1's headline, kept for comparison"},
+                               "what": "the same launch on ONE corpus over and over (served from the 256 MiB Infinity "
+                                       "Cache): round 1's headline, kept for comparison"},
         }
         if degraded:
             out["degraded"] = True
@@ -592,7 +624,7 @@ def main():
     # ---- the other precision modes, same invocation (rank 0's GPU only; never `value`) ------------------
     if world == 1 and not args.no_modes:
         modes = {}
-        for mode in ("fast", "fast24", "exact"):
+        for mode in ("mx", "fast", "fast24", "exact"):
             fl = FLAGS[mode]
             try:
                 for _ in range(3):
@@ -617,7 +649,7 @@ def main():
             for c in replicas[1:]:      # (the replica list has done its work: make room)
                 c.close()
             out["configs"] = {"config3": config3(ctx, corpus, flags)}
-            if args.mode == "fast":
+            if args.mode in ("fast", "mx"):
                 out["configs"]["config2_x10_one_launch"] = long_corpus(ctx, corpus, bank, flags)
         if world == 1 and args.extras:
             out["extras"] = extras(ctx, corpus, bank, flags)

@@ -118,7 +118,10 @@ enum { TSR_OPT_FAST_KERNEL = 1, TSR_OPT_EXACT_KERNEL = 2, TSR_OPT_PART_LAYOUT = 
        /* read-only (tsr_ctx_get_option): 0 = TSR_EXACT has not met the matrix cores on this context yet, 1 = the one-off
         * probe (a small fixed bank scored by the matrix-core kernel and by the vector kernel) matched bit for bit,
         * -1 = it did not and every TSR_EXACT pass of this context stays on the vector kernel (said once on stderr) */
-       TSR_INFO_EXACT_MFMA = 5 };
+       TSR_INFO_EXACT_MFMA = 5,
+       /* read-only: the bank kernel that served the latest scoring pass of this context (TSR_KERNEL_* below; 0 = none yet) */
+       TSR_INFO_LAST_BANK_KERNEL = 6 };
+enum { TSR_KERNEL_EXACT_VALU = 1, TSR_KERNEL_EXACT_MFMA = 2, TSR_KERNEL_INTERLEAVED = 3, TSR_KERNEL_TAP2 = 4, TSR_KERNEL_MX = 5 };
 enum { TSR_OPT_AUTO = 0,
        TSR_FAST_KERNEL_TAP2 = 1, TSR_FAST_KERNEL_INTERLEAVED = 2,
        TSR_EXACT_KERNEL_VALU = 1, TSR_EXACT_KERNEL_MFMA = 2,

@@ -139,6 +139,7 @@ TSR_API int tsr_ctx_get_option(const tsr_ctx *ctx, int option, int *value)
     case TSR_INFO_EXACT_MFMA:  // 1 trusted, -1 probe ran and differed, -2 last probe could not run (it is tried again), 0 not probed
         *value = ctx->exact_mfma_state != 0 ? ctx->exact_mfma_state : (ctx->exact_mfma_could_not_run ? -2 : 0);
         return TSR_OK;
+    case TSR_INFO_LAST_BANK_KERNEL: *value = ctx->last_bank_kernel; return TSR_OK;
     default: break;
     }
     tsr_set_error("tsr_ctx_get_option: unknown option %d", option);
@@ -856,6 +857,7 @@ static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp,
         for (int32_t l : bank->L) Lmin = std::min(Lmin, l);
         if (!d_all && (int64_t)Lmin * bank->D > TSR_FAST_W24_BELOW_TAPS) {
             const int sm = tsr_launch_mx_bank(ctx, bank, cp, cp->d_scores, cp->d_ids);
+            if (sm == TSR_OK) ctx->last_bank_kernel = TSR_KERNEL_MX;
             if (sm != TSR_ERR_UNSUPPORTED) return sm;
         }
     }
@@ -886,6 +888,7 @@ static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp,
             tsr_bank *mb = const_cast<tsr_bank *>(bank);
             int sb = bank->fast[4] ? TSR_OK : tsr_fast_bank_build(ctx, mb, 4);
             if (sb == TSR_OK) sb = tsr_launch_tap2_bank(ctx, bank, cp, d_all ? nullptr : cp->d_scores, d_all ? nullptr : cp->d_ids, d_all);
+            if (sb == TSR_OK) ctx->last_bank_kernel = TSR_KERNEL_TAP2;
             if (sb != TSR_ERR_UNSUPPORTED) return sb;
             if (!bank->fast[4]) mb->tap2_unsupported = true;   // geometry never fits: do not try again
         }
@@ -898,6 +901,7 @@ static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp,
         }
         int s = tsr_launch_fast_bank(ctx, bank, cp, flags, d_all ? nullptr : cp->d_scores,
                                      d_all ? nullptr : cp->d_ids, d_all);
+        if (s == TSR_OK) ctx->last_bank_kernel = TSR_KERNEL_INTERLEAVED;
         if (s != TSR_ERR_UNSUPPORTED) return s;
         // geometry outside the MFMA kernel's envelope: the exact GPU kernel serves it
     }
@@ -910,6 +914,7 @@ static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp,
     int se = TSR_ERR_UNSUPPORTED;
     if (ctx->opt_exact_kernel != TSR_EXACT_KERNEL_VALU && ctx->exact_mfma_state > 0)
         se = tsr_launch_exact_bank_mfma(ctx, bank, cp, (float *)raw);
+    ctx->last_bank_kernel = se == TSR_ERR_UNSUPPORTED ? TSR_KERNEL_EXACT_VALU : TSR_KERNEL_EXACT_MFMA;
     if (se == TSR_ERR_UNSUPPORTED) {
         TSR_TRY(tsr_corpus_need_bytes(ctx, cp));
         se = tsr_launch_exact_bank(ctx, bank, cp->d_feats, cp->P, cp->Dp, (float *)raw);

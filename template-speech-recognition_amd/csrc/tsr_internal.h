@@ -63,6 +63,7 @@ struct tsr_ctx {
     // chain: 0 = not yet checked on this device, 1 = the probe matched the vector kernel bit for bit, -1 = it did not
     // (the vector kernel serves every TSR_EXACT call of this context, said once on stderr)
     int exact_mfma_state = 0;
+    int last_bank_kernel = 0;               // TSR_KERNEL_* of the latest scoring pass (TSR_INFO_LAST_BANK_KERNEL)
     bool exact_mfma_could_not_run = false;  // the last probe failed to run (state stays 0: probed again)
 };
 

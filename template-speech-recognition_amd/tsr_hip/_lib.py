@@ -14,6 +14,8 @@ TSR_PARTS_AUTO, TSR_PARTS_VALU, TSR_PARTS_MFMA = 0, 1, 2
 TSR_OPT_FAST_KERNEL, TSR_OPT_EXACT_KERNEL, TSR_OPT_PART_LAYOUT, TSR_OPT_XCD_MAP = 1, 2, 3, 4
 TSR_OPT_AUTO = 0
 TSR_INFO_EXACT_MFMA = 5
+TSR_INFO_LAST_BANK_KERNEL = 6
+TSR_KERNEL_EXACT_VALU, TSR_KERNEL_EXACT_MFMA, TSR_KERNEL_INTERLEAVED, TSR_KERNEL_TAP2, TSR_KERNEL_MX = 1, 2, 3, 4, 5
 TSR_FAST_KERNEL_TAP2, TSR_FAST_KERNEL_INTERLEAVED = 1, 2
 TSR_EXACT_KERNEL_VALU, TSR_EXACT_KERNEL_MFMA = 1, 2
 TSR_PART_LAYOUT_BYTES, TSR_PART_LAYOUT_BITS = 1, 2
