@@ -2,9 +2,10 @@
 // skew-free Toeplitz product on the block-scaled matrix instruction v_mfma_scale_f32_16x16x128_f8f6f4.
 // (reference: compute_likelihood_linear_filter.pyx:162-175 for the sums, get_train_data.py:962-992 for the bank epilogue)
 //
-// Formulation.  A tile is 16 *pairs* of window starts of one stream position each: row i stands for the starts
-// t0_i and t0_i + 1 (t0_i even inside its utterance), column n = 8 s + m for (shift s, template m), and
-//     acc[i][(s, m)] = sum over tap rows rho = 0 .. Lmax and features d of  X[t0_i + rho][d] * W_m[rho - s][d]
+// Formulation.  A tile is 16 *pairs* of window starts: pair i stands for the starts t0_i and t0_i + 1 (t0_i even
+// inside its utterance), n = 8 s + m for (shift s, template m) -- the weights are the matrix instruction's A operand
+// (rows n), the frames its B operand (columns i) -- and
+//     acc[(s, m)][i] = sum over tap rows rho = 0 .. Lmax and features d of  X[t0_i + rho][d] * W_m[rho - s][d]
 // (weights zero outside 0 <= rho - s < L_m): the score of template m at start t0_i + s, complete in ONE accumulator
 // element -- no skew reduction, no ring, no atomics; the price is Lmax + 1 tap rows instead of Lmax.  Rows are only
 // the starts that some template can score (t <= T - Lmin), so the 31 tail frames of a 200-frame utterance cost nothing.
@@ -99,17 +100,6 @@ struct MxCorpus {   // derived forms of a corpus: bit rows (once), the tile plan
     bool plan_unsupported = false;
 };
 
-__device__ __forceinline__ unsigned orderable(float x)
-{
-    unsigned u = __float_as_uint(x);
-    return u ^ ((unsigned)((int)u >> 31) | 0x80000000u);
-}
-__device__ __forceinline__ float unorderable(unsigned u)
-{
-    u ^= (~(unsigned)((int)u >> 31)) | 0x80000000u;
-    return __uint_as_float(u);
-}
-
 // bit rows at virtual positions from the resident byte rows (one-off per corpus)
 __global__ void mx_pack_bits_kernel(const uint8_t *feats, int Dp, const int64_t *off, const int64_t *voff, int64_t N, int DW,
                                     int64_t Pv, uint32_t *bits)
@@ -168,8 +158,13 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
 #endif
     // ---- everything this workgroup reads from memory besides the bank is requested at once: the group records (one
     //      per thread), the bit rows (five 16-byte pieces per thread), the first K-block's B fragments ----
-    const int n = lane & 15, s = n >> 3, rq = lane >> 4;
-    const MxCol col = a.cols[n];
+    // accumulator register g of this lane is (shift s = lane >> 5, template m = 4 h + g, h = (lane >> 4) & 1) of the
+    // window pair lane & 15: the weights are the A operand, the frames the B operand, so that the templates of a window
+    // lie in registers and across ONE lane pair (lane ^ 16) and the maximum over them is three in-lane compares and one exchange
+    const int s = lane >> 5, h = (lane >> 4) & 1;
+    MxCol col[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) col[g] = a.cols[4 * (lane >> 4) + g];
     MxGroup G = {v_lo, 0, 0, 0};
     if (tid < MX_GROUPS) {
         const int gi = tile_beg * 16 + tid;
@@ -201,7 +196,7 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
         b4[l] = *reinterpret_cast<const i32x4 *>(bp + l * 1536);
         b2[l] = *reinterpret_cast<const i32x2 *>(bp + l * 1536 + 1024 - lane * 8);
     }
-    if (tid == 0) *next_kb = 2 * MX_WAVES;   // (wave w starts with the K-blocks w and w + 8)
+    if (tid == 0) *next_kb = 3 * MX_WAVES;   // (wave w starts with the K-blocks w, w + 8 and w + 16)
     if (tid < MX_GROUPS) {
         g_row[tid] = (G.v0 - v_lo) >> 1;
         g_p0[tid] = G.p0;
@@ -250,18 +245,24 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
     int koff = koff_of(wave);
 #pragma unroll
     for (int j = 0; j < MX_DEPTH; ++j) A[j] = *reinterpret_cast<const i32x4 *>(lds + tb[j] + koff);
-    // Two register sets for the B fragments, used alternately (the loop body exists twice so that no set is ever copied):
-    // one K-block's MFMAs read one set while the next K-block's fragments land in the other, requested piece by piece
-    // between the tile groups.  The draw of a K-block is one K-block ahead of that request, so that nobody waits for the
-    // atomic's return (a wave that waits issues nothing, and its SIMD partner alone runs at half rate).
-    int kb_1 = wave + MX_WAVES;   // the K-block after this one
+    // Three register sets for the B fragments in rotation (the loop body exists three times so that no set is ever copied):
+    // one K-block's MFMAs read one set, the next K-block's fragments sit in the second, and those of the K-block after
+    // that land in the third, requested piece by piece between the tile groups -- one K-block of lead (the last piece
+    // ~700 cycles in front of its use) still showed as a wait at every K-block.  The draw of a K-block is one more
+    // K-block ahead, so that nobody waits for the atomic's return (a wave that waits issues nothing, and its SIMD
+    // partner alone runs at half rate).
+    int kb_1 = wave + MX_WAVES, kb_2 = wave + 2 * MX_WAVES;   // the two K-blocks after this one
     auto kblock = [&](const i32x4 (&c4)[3], const i32x2 (&c2)[3], i32x4 (&n4)[3], i32x2 (&n2)[3]) -> bool {
-        // c: this K-block's fragments; n: the other set, which takes the next K-block's
-        int kb_2 = 0;
-        if (lane == 0) kb_2 = (int)__hip_atomic_fetch_add(next_kb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // c: this K-block's fragments; n: the set that is free now and takes those of the K-block after the next
+        int kb_3 = 0;
+#if MX_ABL & 8   // development ablation: fixed shares (wave w takes K-blocks w, w + 8, ...)
+        kb_3 = kb_2 + MX_WAVES;
+#else
+        if (lane == 0) kb_3 = (int)__hip_atomic_fetch_add(next_kb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
         const bool more = kb_1 < a.NKB;
         const int koff_n = more ? koff_of(kb_1) : koff;
-        const int kb_ld = more ? kb_1 : a.NKB - 1;
+        const int kb_ld = kb_2 < a.NKB ? kb_2 : a.NKB - 1;
         i32x8 B[3];
 #pragma unroll
         for (int l = 0; l < 3; ++l) B[l] = i32x8{c4[l][0], c4[l][1], c4[l][2], c4[l][3], c2[l][0], c2[l][1], 0, 0};
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
         // them the three accumulations of a tile are 48 cycles apart
 #pragma unroll
         for (int j = 0; j < MX_NT; j += 3) {
-            // one piece of the next K-block's fragments per tile group: a wave that issues its six loads
+            // one piece of the fragments of the K-block after the next per tile group: a wave that issues its six loads
             // back to back sits in that sequence for as long as the data takes (vector-memory instructions are issued at
             // the rate the path delivers) and issues no matrix work meanwhile
             // (unconditional -- behind the last K-block it re-reads that one -- so that the sets are plain registers, not
@@ -288,13 +289,13 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u)
-                acc[j + u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(Af[u], B[0], acc[j + u], 4, 2, 0, 0x7f7f7f7f, 0, (int)0x82828282u);
+                acc[j + u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(B[0], Af[u], acc[j + u], 2, 4, 0, (int)0x82828282u, 0, 0x7f7f7f7f);
 #pragma unroll
             for (int u = 0; u < 3; ++u)
-                acc[j + u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(Af[u], B[1], acc[j + u], 4, 2, 0, 0x7f7f7f7f, 0, (int)0x86868686u);
+                acc[j + u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(B[1], Af[u], acc[j + u], 2, 4, 0, (int)0x86868686u, 0, 0x7f7f7f7f);
 #pragma unroll
             for (int u = 0; u < 3; ++u)
-                acc[j + u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(Af[u], B[2], acc[j + u], 4, 2, 0, 0x7f7f7f7f, 0, (int)0x8a8a8a8au);
+                acc[j + u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(B[2], Af[u], acc[j + u], 2, 4, 0, (int)0x8a8a8a8au, 0, 0x7f7f7f7f);
             // (behind the group's matrix instructions, which read the ring slots these reads refill: no copies of the slots)
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
@@ -307,15 +308,26 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
                 A[(j + u) % MX_DEPTH] = *reinterpret_cast<const i32x4 *>(lds + (jn < MX_NT ? tb[jn] + koff : tb[jn - MX_NT] + koff_n));
 #endif
             }
+#if !(MX_ABL & 16)
             __builtin_amdgcn_sched_barrier(0);   // (the compiler otherwise sinks the reads to just in front of their use)
+#endif
         }
         koff = koff_n;
-        kb_1 = __builtin_amdgcn_readfirstlane(kb_2);
+        kb_1 = kb_2;
+        kb_2 = __builtin_amdgcn_readfirstlane(kb_3);
         return more;
     };
-    i32x4 d4[3] = {b4[0], b4[1], b4[2]};
-    i32x2 d2[3] = {b2[0], b2[1], b2[2]};
-    while (kblock(b4, b2, d4, d2) && kblock(d4, d2, b4, b2)) {
+    i32x4 d4[3], e4[3] = {b4[0], b4[1], b4[2]};
+    i32x2 d2[3], e2[3] = {b2[0], b2[1], b2[2]};
+    {   // the second K-block's fragments (the first one's were requested at the top of the kernel)
+        const unsigned char *nb = a.B + (size_t)(kb_1 < a.NKB ? kb_1 : a.NKB - 1) * (3 * 1536) + lane * 16;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            d4[l] = *reinterpret_cast<const i32x4 *>(nb + l * 1536);
+            d2[l] = *reinterpret_cast<const i32x2 *>(nb + l * 1536 + 1024 - lane * 8);
+        }
+    }
+    while (kblock(b4, b2, e4, e2) && kblock(d4, d2, b4, b2) && kblock(e4, e2, d4, d2)) {
     }
 #ifdef MX_PRIO
     __builtin_amdgcn_s_setprio(0);
@@ -358,77 +370,52 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
     }
     MX_STAMP(7)
     f32x4 sum[3] = {own[0], own[1], own[2]};
-    i32x4 RM[3];
-    int fp0[3], frem[3], tp0[3], trem[3];
+    int gp0[3], grem[3];   // the lane's window pair (lane & 15) of each tile: stream frame of its first start, frames left
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
-        RM[u] = *reinterpret_cast<const i32x4 *>(g_rem + jj[u] * 16 + 4 * rq);   // frames left, the lane's four rows
-        fp0[u] = g_p0[jj[u] * 16 + ((lane >> 1) & 15)];                         // lane < 32: the frame lane of the tile
-        frem[u] = g_rem[jj[u] * 16 + ((lane >> 1) & 15)];
-        tp0[u] = g_p0[jj[u] * 16 + (lane & 15)];                                // lane < 16: row lane of the tile
-        trem[u] = g_rem[jj[u] * 16 + (lane & 15)];
+        gp0[u] = g_p0[jj[u] * 16 + (lane & 15)];
+        grem[u] = g_rem[jj[u] * 16 + (lane & 15)];
     }
 #pragma unroll
     for (int r = 0; r < 7; ++r)   // (reads only: the compiler keeps as many in flight as it has registers for)
 #pragma unroll
         for (int u = 0; u < 3; ++u) sum[u] += *reinterpret_cast<const f32x4 *>(lds + ((size_t)(jj[u] * 7 + r) << 10) + lane * 16);
-    unsigned best[3][4];
-    int first[3][4];
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const bool valid = s + col.L <= RM[u][g];   // the window of template m at t0 + s lies inside the utterance
-            const float val = (valid ? sum[u][g] * col.inv_scale : 0.0f) + col.c;   // (tail rule: 0 + c_m)
-            // max over the eight templates of this shift (lanes 8 s .. 8 s + 7), the lowest id among the maxima: three DPP
-            // exchanges on the orderable score, then the first lane of the eight that holds the maximum
-            const unsigned ov = orderable(val);
-            unsigned b = ov;
-            b = max(b, (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
-            b = max(b, (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
-            b = max(b, (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x141, 0xf, 0xf, false));   // row_half_mirror
-            const unsigned long long hit = __ballot(ov == b);
-            best[u][g] = b;
-            first[u][g] = __builtin_ctz((unsigned)(hit >> (lane & 56)) & 0xffu);   // (template ids are the lane order)
-        }
-    }
-    // a tile's 32 results (rows x shifts) go through LDS -- the tile's own slots, read above and free now -- so that they
-    // leave as two coalesced stores instead of eight scattered ones
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-        unsigned *const res = reinterpret_cast<unsigned *>(lds + ((size_t)(jj[u] * 7) << 10));
-        if ((n & 7) == 0 && ok[u]) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                res[2 * (4 * rq + g) + s] = best[u][g];
-                res[32 + 2 * (4 * rq + g) + s] = (unsigned)first[u][g];
-            }
-        }
-    }
-    unsigned sc[3], id[3];
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {   // (same wave: LDS operations execute in order)
-        const unsigned *const res = reinterpret_cast<const unsigned *>(lds + ((size_t)(jj[u] * 7) << 10));
-        sc[u] = res[lane & 31];
-        id[u] = res[32 + (lane & 31)];
-    }
     MX_STAMP(8)
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
-        if (ok[u] && lane < 32 && (lane & 1) < frem[u]) {
-            a.scores[fp0[u] + (lane & 1)] = unorderable(sc[u]);
-            a.ids[fp0[u] + (lane & 1)] = (int)id[u];
+        // scale, tail rule (0 + c_m where the window leaves the utterance), + c_m; the first maximum over the lane's four
+        // templates, then against the other four of the partner lane: the lower id wins a tie
+        float bv = 0;
+        int bm = 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const bool valid = s + col[g].L <= grem[u];
+            const float val = (valid ? sum[u][g] * col[g].inv_scale : 0.0f) + col[g].c;
+            if (g == 0 || val > bv) {
+                bv = val;
+                bm = 4 * h + g;
+            }
+        }
+        const float ov = __shfl_xor(bv, 16);
+        const int om = __shfl_xor(bm, 16);
+        if (h ? ov >= bv : ov > bv) {
+            bv = ov;
+            bm = om;
+        }
+        if (ok[u] && h == 0 && s < grem[u]) {   // lanes 0..15: the first start of a pair, lanes 32..47: the second
+            a.scores[gp0[u] + s] = bv;
+            a.ids[gp0[u] + s] = bm;
         }
     }
-    // the last group of an utterance: the frames behind its two starts score max_m c_m (every template is in its tail
-    // there).  Rows are flagged by lanes 0..15, the whole wave then fills one flagged row after the other.
+    // the last pair of an utterance: the frames behind its two starts score max_m c_m (every template is in its tail
+    // there).  Pairs are flagged by lanes 0..15, the whole wave then fills one flagged pair after the other.
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
-        unsigned long long todo = __ballot(ok[u] && lane < 16 && trem[u] > 2 && trem[u] < a.Lmin + 2);
+        unsigned long long todo = __ballot(ok[u] && lane < 16 && grem[u] > 2 && grem[u] < a.Lmin + 2);
         while (todo) {
             const int i = __builtin_ctzll(todo);
             todo &= todo - 1;
-            const int bp = __builtin_amdgcn_readlane(tp0[u], i), br = __builtin_amdgcn_readlane(trem[u], i);
+            const int bp = __builtin_amdgcn_readlane(gp0[u], i), br = __builtin_amdgcn_readlane(grem[u], i);
             for (int t = 2 + lane; t < br; t += 64) {
                 a.scores[bp + t] = a.cmax;
                 a.ids[bp + t] = a.idmax;

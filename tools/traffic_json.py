@@ -4,6 +4,8 @@ roofline.traffic.  gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide co
 (MI355X_MICROARCH.md, HBM section); both counters are in KiB."""
 import json, re, sys
 fetch_txt, write_txt, mode, out = sys.argv[1:5]
+working_set = sys.argv[5] if len(sys.argv) > 5 else None   # (round 4: given by the caller)
+how = sys.argv[6] if len(sys.argv) > 6 else "--replicas 16 (tools/profile_r03.sh traffic)"
 
 
 def dominant(path, counter):
@@ -25,11 +27,12 @@ kf, nf, fetch = dominant(fetch_txt, "FETCH_SIZE")
 kw, nw, write = dominant(write_txt, "WRITE_SIZE")
 assert kf == kw, (kf, kw)
 alg = 366 * 200000
-j = {"mode": mode, "kernel": kf.split("(")[0].replace("void ", ""),
-     "working_set": "16 device-resident copies of the config-2 corpus (1.2 GB, 4.7x the 256 MiB Infinity Cache), each launch "
-                    "streams its 73.6 MB of frames from HBM",
-     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 3 --warmup 1 --replicas 16 "
-                "--no-cpu-baseline --no-modes --mode %s (two separate passes; tools/profile_r03.sh traffic)" % mode,
+kname = re.search(r"(\w+_bank_kernel(<[^>]*>)?)", kf)
+j = {"mode": mode, "kernel": kname.group(1) if kname else kf,
+     "working_set": working_set or "16 device-resident copies of the config-2 corpus (1.2 GB, 4.7x the 256 MiB Infinity Cache), each launch "
+                                   "streams its 73.6 MB of frames from HBM",
+     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 3 --warmup 1 "
+                "--no-cpu-baseline --no-modes --mode %s %s (two separate passes)" % (mode, how),
      "counters": {"FETCH_SIZE": {"launches": nf, "mean_KiB": fetch}, "WRITE_SIZE": {"launches": nw, "mean_KiB": write}},
      "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream -> read side x2 "
                    "(MI355X_MICROARCH.md, HBM)",
