@@ -4,8 +4,23 @@ cannot drift from them (round-2 review, item 7/9):
 Every cell names the file it comes from; a missing file yields "n/a" (never a remembered number)."""
 import csv, json, os, re, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-R = next((a for a in sys.argv[1:] if re.fullmatch(r"r\d\d", a)), "r03")
-P = lambda name: os.path.join(ROOT, "profiles", "%s_%s" % (R, name))
+R = next((a for a in sys.argv[1:] if re.fullmatch(r"r\d\d", a)), "r04")
+ROUNDS = ["r%02d" % k for k in range(int(R[1:]), 0, -1)]   # newest first: a file missing in round R is taken from the round before
+
+
+def P(name):
+    """Path of the newest profiles/rNN_<name> at or before round R (a row whose evidence was not re-collected this round
+    keeps citing the file it was measured in)."""
+    for r in ROUNDS:
+        path = os.path.join(ROOT, "profiles", "%s_%s" % (r, name))
+        if os.path.exists(path):
+            return path
+    return os.path.join(ROOT, "profiles", "%s_%s" % (R, name))
+
+
+def tag(name):
+    """The file name a cell cites: `rNN_<name>` of the round the file was found in."""
+    return os.path.basename(P(name))
 
 
 def kavg(csv_name, needle):
@@ -51,22 +66,49 @@ def f(x, fmt="%.1f", na="n/a"):
 rows = []
 bench = jload("bench_line.json")
 ALG_FLOPS, ALG_BYTES = 31.15008e9, 73.2e6
+# ---- the headline kernel of round 4: the Toeplitz form on the block-scaled matrix instruction ----------------------
+usx, callsx = kavg("bench_mx_kernel_stats.csv", "mx_bank_kernel")
+if bench and bench.get("config", {}).get("mode") == "mx":
+    evx = bench["roofline"]["kernel_ms_per_launch"] * 1e3
+    trx = jload("traffic_mx.json")
+    busyx, sqbx = pmc("pmc_sq1_mx.txt", "mx_bank_kernel", "SQ_VALU_MFMA_BUSY_CYCLES"), pmc("pmc_sq1_mx.txt", "mx_bank_kernel", "SQ_BUSY_CYCLES")
+    rows.append(("`mx_bank_kernel<3>` (`TSR_FAST|TSR_MX`: 13-bit weights, fp6 x fp4, Toeplitz form)", "config 2, every launch reads its corpus' bit rows from HBM",
+                 "31.15 Gflop, 73.2 MB (366 B/frame)",
+                 "%s us hipEvents in `bench.py` (`%s`); %s us rocprofv3 average of %d launches of a profiled run (`%s`)"
+                 % (f(evx, "%.2f"), tag("bench_line.json"), f(usx, "%.2f"), callsx, tag("bench_mx_kernel_stats.csv")),
+                 "%s TB/s of algorithmic bytes = %s of the 8 TB/s HBM peak; %s Tflop/s = %s of the 10 PF fp6 peak (%s counting the three digit products, K padding and the 33rd tap row); "
+                 "PMC traffic %s MB = %sx algorithmic (`%s`: the kernel reads bit rows, 48 B per frame); matrix pipe busy %s of the launch at the nominal 16 cycles per instruction (`%s`)"
+                 % (f(ALG_BYTES / evx / 1e6, "%.2f"), f(ALG_BYTES / evx / 1e6 / 8, "%.3f"), f(ALG_FLOPS / evx / 1e6, "%.0f"), f(ALG_FLOPS / evx / 1e6 / 10000, "%.3f"),
+                    f(bench["roofline"]["mfma"]["issued"]["frac_of_peak"], "%.2f"),
+                    f(trx["hbm_bytes_per_launch"] / 1e6 if trx else None), f(trx["ratio_to_algorithmic"] if trx else None, "%.2f"), tag("traffic_mx.json"),
+                    f(100.0 * busyx / (1024.0 * sqbx / 32.0) if busyx and sqbx else None, "%.0f %%"), tag("pmc_sq1_mx.txt")),
+                 "per-wave issue of the scaled matrix instruction (two waves per SIMD end at ~16 cycles per instruction and SIMD, `r04_mx_rate_ubench.txt`) + the un-overlapped staging / exchange / finishing phases (section 4.0)"))
+    x10 = bench.get("configs", {}).get("config2_x10_one_launch")
+    if x10:
+        rows.append(("`mx_bank_kernel<3>`, 10 000 utterances in one launch", "config 2 ten times over", "311.5 Gflop, 732 MB",
+                     "%s us per launch = %s us per 1000 utterances (`%s`, `configs.config2_x10_one_launch`)"
+                     % (f(x10["kernel_ms_per_launch"] * 1e3, "%.1f"), f(x10["kernel_us_per_1000_utterances"], "%.2f"), tag("bench_line.json")),
+                     "%s TB/s of algorithmic bytes" % f(x10["hbm_gbs_alg"] / 1e3, "%.2f"),
+                     "as above: one workgroup per CU and round, nothing to amortise over a longer launch"))
 # ---- the dominant kernel ------------------------------------------------------------------------------------------
 us, calls = kavg("bench_fast_kernel_stats.csv", "tap2_bank_kernel")
-ev = bench["roofline"]["kernel_ms_per_launch"] * 1e3 if bench else None
+ev = None
+if bench:
+    ev = (bench["modes"]["fast"]["kernel_ms_per_launch"] if bench.get("config", {}).get("mode") == "mx" and "fast" in bench.get("modes", {})
+          else bench["roofline"]["kernel_ms_per_launch"]) * 1e3
 tr = jload("traffic_fast.json")
 busy, sqb = pmc("pmc_sq1.txt", "tap2_bank_kernel", "SQ_VALU_MFMA_BUSY_CYCLES"), pmc("pmc_sq1.txt", "tap2_bank_kernel", "SQ_BUSY_CYCLES")
 wavecyc = pmc("pmc_sq1.txt", "tap2_bank_kernel", "SQ_WAVE_CYCLES")
 rows.append(("`tap2_bank_kernel<23,0>` (`TSR_FAST`, narrow rows)", "config 2, every launch streams its frames from HBM",
              "31.15 Gflop, 73.2 MB (366 B/frame)",
-             "%s us hipEvents in `bench.py` (`%s_bench_line.json`); %s us rocprofv3 average of %d launches of a profiled run (`%s_bench_fast_kernel_stats.csv`)"
-             % (f(ev, "%.2f"), R, f(us, "%.2f"), calls, R),
-             "%s Tflop/s = %s of the 5 PF int8 peak; %s TB/s = %s of HBM; PMC traffic %s MB = %sx algorithmic (`%s_traffic_fast.json`); matrix pipe busy %s of the launch (`SQ_VALU_MFMA_BUSY_CYCLES` / 1024 SIMDs / launch cycles, `%s_pmc_sq1.txt`)"
+             "%s us hipEvents in `bench.py` (`%s`); %s us rocprofv3 average of %d launches of a profiled run (`%s`)"
+             % (f(ev, "%.2f"), tag("bench_line.json"), f(us, "%.2f"), calls, tag("bench_fast_kernel_stats.csv")),
+             "%s Tflop/s = %s of the 5 PF int8 peak; %s TB/s = %s of HBM; PMC traffic %s MB = %sx algorithmic (`%s`); matrix pipe busy %s of the launch (`SQ_VALU_MFMA_BUSY_CYCLES` / 1024 SIMDs / launch cycles, `%s`)"
              % (f(ALG_FLOPS / ev / 1e6 if ev else None, "%.0f"), f(ALG_FLOPS / ev / 1e6 / 5000 if ev else None, "%.3f"),
                 f(ALG_BYTES / ev / 1e6 if ev else None, "%.2f"), f(ALG_BYTES / ev / 1e6 / 8 if ev else None, "%.3f"),
-                f(tr["hbm_bytes_per_launch"] / 1e6 if tr else None), f(tr["ratio_to_algorithmic"] if tr else None, "%.2f"), R,
+                f(tr["hbm_bytes_per_launch"] / 1e6 if tr else None), f(tr["ratio_to_algorithmic"] if tr else None, "%.2f"), tag("traffic_fast.json"),
                 # SQ_BUSY_CYCLES sums 32 shader engines (8 XCDs x 4): / 32 = cycles of the launch; 1024 SIMDs on the chip
-                f(100.0 * busy / (1024.0 * sqb / 32.0) if busy and sqb else None, "%.0f %%"), R),
+                f(100.0 * busy / (1024.0 * sqb / 32.0) if busy and sqb else None, "%.0f %%"), tag("pmc_sq1.txt")),
              "instruction issue beside the matrix pipe + the per-workgroup prologue (section 4.1)"))
 if bench and "modes" in bench:
     for mode, kern, note in (("fast24", "alt_bank_kernel<12,3>", "three limbs"), ("exact", "exact_mfma_kernel", "scalar issue (operand funnel)")):
@@ -74,14 +116,14 @@ if bench and "modes" in bench:
         if m:
             us2, c2 = kavg("bench_%s_kernel_stats.csv" % mode, kern.split("<")[0])
             rows.append(("`%s` (`%s`)" % (kern, "TSR_FAST|TSR_W24" if mode == "fast24" else "TSR_EXACT"), "config 2", "same",
-                         "%s us hipEvents (`%s_bench_line.json`, `modes.%s`); %s us rocprofv3 average (`%s_bench_%s_kernel_stats.csv`)"
-                         % (f(m["kernel_ms_per_launch"] * 1e3, "%.1f"), R, mode, f(us2, "%.1f"), R, mode),
+                         "%s us hipEvents (`%s`, `modes.%s`); %s us rocprofv3 average (`%s`)"
+                         % (f(m["kernel_ms_per_launch"] * 1e3, "%.1f"), tag("bench_line.json"), mode, f(us2, "%.1f"), tag("bench_%s_kernel_stats.csv" % mode)),
                          "%s Tflop/s algorithmic; %s M frames/s" % (f(m["alg_tflops"], "%.0f"), f(m["frames_per_s"] / 1e6, "%.0f")), note))
-    x10 = bench.get("configs", {}).get("config2_x10_one_launch")
+    x10 = bench.get("configs", {}).get("config2_x10_one_launch") if bench.get("config", {}).get("mode") != "mx" else None
     if x10:
         rows.append(("`tap2_bank_kernel<23,0>`, 10 000 utterances in one launch", "config 2 ten times over (prologue amortised 10x)", "311.5 Gflop, 732 MB",
-                     "%s us per launch = %s us per 1000 utterances (`%s_bench_line.json`, `configs.config2_x10_one_launch`)"
-                     % (f(x10["kernel_ms_per_launch"] * 1e3, "%.1f"), f(x10["kernel_us_per_1000_utterances"], "%.2f"), R),
+                     "%s us per launch = %s us per 1000 utterances (`%s`, `configs.config2_x10_one_launch`)"
+                     % (f(x10["kernel_ms_per_launch"] * 1e3, "%.1f"), f(x10["kernel_us_per_1000_utterances"], "%.2f"), tag("bench_line.json")),
                      "%s of the int8 peak; %s TB/s of algorithmic bytes" % (f(x10["frac_of_int8_peak"], "%.3f"), f(x10["hbm_gbs_alg"] / 1e3, "%.2f")),
                      "the steady-state loop (matrix pipe 81 % busy inside it)"))
 # ---- config 3 -----------------------------------------------------------------------------------------------------
@@ -98,16 +140,16 @@ if c3["code_parts_mfma_kernel"][0]:
     rows.append(("config-3 chain: setup + `code_parts_mfma_kernel<7>` + recheck + `spread_lane_bits_kernel` (dilation into the bit form) + `fast_bank_kernel<11,2,bits>` (6 K-phases in %s launch%s) + epilogue"
                  % ("one" if per_pass < 1.5 else "%d" % round(per_pass), "" if per_pass < 1.5 else "es"),
                  "config 3: 8.2 M locations x 50 parts; D = 2050 bank", "164 + 177 Gflop, 73.2 MB algorithmic",
-                 "%s + %s + %s + %s + %s = %s us of kernels (`%s_config3_kernel_stats.csv`)"
-                 % (f(setup), f(c3["code_parts_mfma_kernel"][0]), f(c3["code_parts_recheck_kernel"][0]), f(c3["spread_"][0]), f(bank), f(tot), R),
-                 "%s Tflop/s over the chain; PMC traffic %s MB = %sx algorithmic (`%s_config3_traffic.json`; round 2: ~950 MB by its own sizes)"
-                 % (f(341e9 / tot / 1e6, "%.0f"), f(t3["hbm_bytes_per_chain"] / 1e6 if t3 else None, "%.0f"), f(t3["ratio_to_algorithmic"] if t3 else None, "%.1f"), R),
+                 "%s + %s + %s + %s + %s = %s us of kernels (`%s`)"
+                 % (f(setup), f(c3["code_parts_mfma_kernel"][0]), f(c3["code_parts_recheck_kernel"][0]), f(c3["spread_"][0]), f(bank), f(tot), tag("config3_kernel_stats.csv")),
+                 "%s Tflop/s over the chain; PMC traffic %s MB = %sx algorithmic (`%s`; round 2: ~950 MB by its own sizes)"
+                 % (f(341e9 / tot / 1e6, "%.0f"), f(t3["hbm_bytes_per_chain"] / 1e6 if t3 else None, "%.0f"), f(t3["ratio_to_algorithmic"] if t3 else None, "%.1f"), tag("config3_traffic.json")),
                  "instructions beside the matrix cores (coder: three per part-slot key; bank: 22 MFMAs per skew emission)"))
 # ---- config 4 share -----------------------------------------------------------------------------------------------
 us4, c4 = kavg("c45_kernel_stats.csv", "tap2_bank_kernel")
 if us4:
     rows.append(("`tap2_bank_kernel<23,3>` (10 column groups, XCD-aware) + key decode", "config 4 share: 1250 utterances, M = 64", "338 Gflop (valid windows)",
-                 "%s us rocprofv3 average (`%s_c45_kernel_stats.csv`); per-pass hipEvent times of all five variants: `%s_config45_timing.txt`" % (f(us4), R, R),
+                 "%s us rocprofv3 average (`%s`); per-pass hipEvent times of all five variants: `%s`" % (f(us4), tag("c45_kernel_stats.csv"), tag("config45_timing.txt")),
                  "%s Tflop/s = %s of the int8 peak" % (f(338e9 / us4 / 1e6, "%.0f"), f(338e9 / us4 / 1e6 / 5000, "%.3f")), "as config 2"))
 # ---- next rows ----------------------------------------------------------------------------------------------------
 for csvn, needle, label, work, alg, bound in (
@@ -118,7 +160,7 @@ for csvn, needle, label, work, alg, bound in (
     u, c = kavg(csvn, needle)
     if u:
         extra = ("%s Tflop/s" % f(24.5e9 / u / 1e6, "%.1f")) if ("isolated" in needle or "iso_" in needle) else ("%s TB/s" % f(146e6 / u / 1e6, "%.2f"))
-        rows.append((label, work, alg, "%s us rocprofv3 average of %d (`%s_%s`)" % (f(u), c, R, csvn), extra, bound))
+        rows.append((label, work, alg, "%s us rocprofv3 average of %d (`%s`)" % (f(u), c, tag(csvn)), extra, bound))
 out = ["| kernel | workload | algorithmic work per launch | time (source) | achieved | bound by |", "|---|---|---|---|---|---|"]
 out += ["| " + " | ".join(r) + " |" for r in rows]
 table = "\n".join(out)
@@ -127,6 +169,6 @@ if "--write" in sys.argv:
     s = open(path).read()
     a, b = s.index("<!-- table:begin -->"), s.index("<!-- table:end -->")
     open(path, "w").write(s[:a] + "<!-- table:begin -->\n" + table + "\n" + s[b:])
-    print("DESIGN.md table rewritten from profiles/%s_*" % R)
+    print("DESIGN.md table rewritten from profiles/ (newest file per row, round %s and before)" % R)
 else:
     print(table)

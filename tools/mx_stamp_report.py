@@ -20,5 +20,8 @@ if x.max() > 0:
     print("  inside the fill: loads landed after %.0f cycles (mean; max %.0f)" % ((x[:, 0] - t[:, 0]).mean(), (x[:, 0] - t[:, 0]).max()))
     print("  inside the finish: own sums picked %.0f, first tile finished after another %.0f, the rest %.0f" %
           ((x[:, 1] - t[:, 4]).mean(), (x[:, 2] - x[:, 1]).mean(), (t[:, 5] - x[:, 2]).mean()))
+if d.shape[1] > 11 and d[:, 11].max() > 0:
+    kc = d[:, 11]
+    print("  K-blocks per wave (mean by wave id): " + " ".join("%.1f" % kc[d[:, 1] == w].mean() for w in range(8)) + "; cycles per K-block: " + " ".join("%.0f" % (ph[d[:, 1] == w, 2] / kc[d[:, 1] == w]).mean() for w in range(8)))
 g0 = t[:, 0].min()
 print("  first wave start -> last wave end: %.0f cycles; last start %.0f" % (t[:, 5].max() - g0, t[:, 0].max() - g0))

@@ -82,6 +82,43 @@ __global__ __launch_bounds__(W * 256, W) void loop_like(int steps, unsigned long
     }
 }
 
+template <int W, int NT>
+__global__ __launch_bounds__(W * 256, W) void loop_like_t(int steps, unsigned long long *out, float *sink, const i32x8 *ain, const i32x8 *bin)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    i32x8 A[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { A[i] = ain[(lane + i) & 63]; A[i][4] = A[i][5] = A[i][6] = A[i][7] = 0; }
+    i32x8 B[3] = {bin[lane], bin[64 + lane], bin[128 + lane]};
+    f32x4 acc[NT] = {};
+    unsigned long long t0, r0, t1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
+    for (int s = 0; s < steps; ++s) {
+#pragma unroll
+        for (int j = 0; j < NT; j += 3) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                acc[j + u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(B[0], A[(j + u) % 7], acc[j + u], 2, 4, 0, (int)0x82828282u, 0, 0x7f7f7f7f);
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                acc[j + u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(B[1], A[(j + u) % 7], acc[j + u], 2, 4, 0, (int)0x86868686u, 0, 0x7f7f7f7f);
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                acc[j + u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(B[2], A[(j + u) % 7], acc[j + u], 2, 4, 0, (int)0x8a8a8a8au, 0, 0x7f7f7f7f);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
+    float x = 0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) x += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    if (x == 1.2345f) sink[0] = x;
+    if (lane == 0) {
+        out[(blockIdx.x * 16 + wave) * 2] = t1 - t0;
+        out[(blockIdx.x * 16 + wave) * 2 + 1] = r1 - r0;
+    }
+}
+
 template <int W, int NT> int run_like(unsigned long long *dout, float *dsink, const i32x8 *da, const i32x8 *db)
 {
     const int steps = 400;
@@ -95,7 +132,28 @@ template <int W, int NT> int run_like(unsigned long long *dout, float *dsink, co
     for (int i = 0; i < 256 * 16; ++i)
         if (h[2 * i]) { cyc += h[2 * i]; real += h[2 * i + 1]; ++n; }
     const double per = cyc / n / (steps * 3.0 * NT);
-    printf("%d wave(s) per SIMD, loop-like, %d accumulators: %.2f cycles per instruction per wave = %.2f per SIMD, clock %.3f GHz\n", W, NT, per, per / W,
+    double lo = 1e30, hi = 0;
+    for (int i = 0; i < 256 * 16; ++i)
+        if (h[2 * i]) { lo = lo < (double)h[2 * i] ? lo : (double)h[2 * i]; hi = hi > (double)h[2 * i] ? hi : (double)h[2 * i]; }
+    printf("%d wave(s) per SIMD, loop-like, %d accumulators: %.2f cycles per instruction per wave (fastest wave %.2f, slowest %.2f: the job ends at %.2f per SIMD), clock %.3f GHz\n",
+           W, NT, per, lo / (steps * 3.0 * NT), hi / (steps * 3.0 * NT), hi / (steps * 3.0 * NT) / W, cyc / real / 10.0);
+    return 0;
+}
+
+template <int W, int NT> int run_like_t(unsigned long long *dout, float *dsink, const i32x8 *da, const i32x8 *db)
+{
+    const int steps = 400;
+    CK(hipMemset(dout, 0, 256 * 16 * 16));
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((loop_like_t<W, NT>), dim3(256), dim3(W * 256), 0, 0, steps, dout, dsink, da, db);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h(256 * 16 * 2);
+    CK(hipMemcpy(h.data(), dout, h.size() * 8, hipMemcpyDeviceToHost));
+    double cyc = 0, real = 0;
+    int n = 0;
+    for (int i = 0; i < 256 * 16; ++i)
+        if (h[2 * i]) { cyc += h[2 * i]; real += h[2 * i + 1]; ++n; }
+    const double per = cyc / n / (steps * 3.0 * NT);
+    printf("%d wave(s) per SIMD, loop-like with swapped operand roles, %d accumulators: %.2f cycles per instruction per wave = %.2f per SIMD, clock %.3f GHz\n", W, NT, per, per / W,
            cyc / real / 10.0);
     return 0;
 }
@@ -131,6 +189,41 @@ int main()
     CK(hipMalloc(&da, a.size() * 4)); CK(hipMalloc(&db, b.size() * 4)); CK(hipMalloc(&dout, 256 * 16 * 16)); CK(hipMalloc(&dsink, 16));
     CK(hipMemcpy(da, a.data(), a.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(db, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+    {   // does the instruction's time depend on the operand values?  The same loop on three operand sets.
+        std::vector<unsigned> a2(64 * 8, 0), b2(192 * 8, 0), b3(192 * 8, 0);
+        for (int l = 0; l < 64; ++l)
+            for (int e = 0; e < 32; ++e)
+                if (rnd() % 100 < 22) a2[l * 8 + (e >> 3)] |= 2u << ((e & 7) * 4);          // binary frames, 22 % set, as fp4 1.0
+        for (int f = 0; f < 192; ++f)
+            for (int e = 0; e < 32; ++e) {
+                const int dgt = (int)(rnd() % 17) - 8;                                       // balanced digits -8 .. 8 (sign-magnitude fp6)
+                const unsigned code = (unsigned)(dgt < 0 ? -dgt : dgt) | (dgt < 0 ? 0x20u : 0u);
+                const int bit = e * 6;
+                b2[f * 8 + (bit >> 5)] |= code << (bit & 31);
+                if ((bit & 31) > 26) b2[f * 8 + (bit >> 5) + 1] |= code >> (32 - (bit & 31));
+            }
+        for (size_t i = 0; i < b3.size(); ++i) b3[i] = (i % 8) < 6 ? (rnd() << 8) ^ rnd() : 0;   // random bits in every field
+        unsigned *da2, *db2, *db3;
+        CK(hipMalloc(&da2, a2.size() * 4)); CK(hipMalloc(&db2, b2.size() * 4)); CK(hipMalloc(&db3, b3.size() * 4));
+        CK(hipMemcpy(da2, a2.data(), a2.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(db2, b2.data(), b2.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(db3, b3.data(), b3.size() * 4, hipMemcpyHostToDevice));
+        printf("operand sets -- masked sparse (the rows below):\n");
+        run_like<2, 21>(dout, dsink, (i32x8 *)da, (i32x8 *)db);
+        printf("more accumulators (more registers per wave):\n");
+        run_like<2, 42>(dout, dsink, (i32x8 *)da2, (i32x8 *)db2);
+        run_like<2, 48>(dout, dsink, (i32x8 *)da2, (i32x8 *)db2);
+        printf("operand sets -- like the kernel's (22 %% of the fp4 frames set, balanced fp6 digits -8 .. 8):\n");
+        run_like<2, 21>(dout, dsink, (i32x8 *)da2, (i32x8 *)db2);
+        printf("operand sets -- random bits in every fp6 field, kernel-like frames:\n");
+        run_like<2, 21>(dout, dsink, (i32x8 *)da2, (i32x8 *)db3);
+        printf("operand roles swapped (A = fp6 weights, B = fp4 frames), kernel-like operands:\n");
+        run_like_t<2, 21>(dout, dsink, (i32x8 *)db2, (i32x8 *)da2);
+        run_like_t<1, 21>(dout, dsink, (i32x8 *)db2, (i32x8 *)da2);
+        printf("operand sets -- all zero:\n");
+        CK(hipMemset(da2, 0, a2.size() * 4)); CK(hipMemset(db2, 0, b2.size() * 4));
+        run_like<2, 21>(dout, dsink, (i32x8 *)da2, (i32x8 *)db2);
+    }
     run<1, 1, 0>(dout, dsink, (i32x8 *)da, (i32x8 *)db);
     run<1, 1, 1>(dout, dsink, (i32x8 *)da, (i32x8 *)db);
     run<1, 0, 0>(dout, dsink, (i32x8 *)da, (i32x8 *)db);
