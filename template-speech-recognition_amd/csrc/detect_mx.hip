@@ -63,7 +63,9 @@ struct MxArgs {
     const MxCol *cols;        // [16]
     float *scores;
     int32_t *ids;
+    const int32_t *kq;        // [NKB][4] LDS byte offset of the chunk that feeds K-quarter q of K-block kb (frame row 0 of a pair)
     int n_groups, NKB, KBF, NR, Lmin, idmax;
+    int CH, nfull, packed;    // chunk arrays per frame parity; full 32-feature chunks of a row; leftover features of four tap rows share a chunk
     float cmax;
     unsigned long long *dbg;  // -DTSR_STAMP builds only: [workgroup][wave][16] s_memtime stamps
 };
@@ -82,7 +84,8 @@ struct MxArgs {
 #endif
 
 struct MxBank {
-    int KBF = 0, ROWS = 0, NKB = 0, NR = 0, Lmin = 0, Lmax = 0, idmax = 0;
+    int KBF = 0, ROWS = 0, NKB = 0, NR = 0, Lmin = 0, Lmax = 0, idmax = 0, CH = 0, nfull = 0, packed = 0;
+    int32_t *d_kq = nullptr;
     float cmax = 0;
     unsigned char *d_B = nullptr;
     MxCol *d_cols = nullptr;
@@ -134,11 +137,13 @@ constexpr int MX_IMAGE = MX_LDS - MX_STASH;       // bytes the frame image may t
 constexpr int MX_DEPTH = 7;                       // A fragments in flight per wave
 static_assert(MX_NT % MX_DEPTH == 0 && MX_NT % 3 == 0, "the fragment ring must line up across K-blocks: tile j lives in A[j % MX_DEPTH]");
 
-template <int KBF>
+// FULL: the row has exactly 4 KBF chunk arrays (every 16-byte piece of a bit row fills four of them: no per-chunk checks)
+template <int KBF, bool FULL>
 __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int CH = 4 * KBF, DW = 4 * KBF;
+    constexpr int DW = 4 * KBF;
+    const int CH = a.CH, nfull = a.nfull;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int4 wg = a.wg[blockIdx.x];
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
     // slots; at most 2 * KBF * NR <= 2496 pieces = five per thread
     const int nrows = (nfr + 1) >> 1;
     u32x4 piece[5];
-    int dst[5];
+    int dst[5], cpiece[5];
 #pragma unroll
     for (int it = 0; it < 5; ++it) {
         const int idx = tid + it * (MX_WAVES * 64);
@@ -183,6 +188,7 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
         const int fr = 2 * r + plane;
         piece[it] = u32x4{0, 0, 0, 0};
         dst[it] = -1;
+        cpiece[it] = kbf;
         if (pass < 2 * KBF) {
             dst[it] = ((plane * CH + 4 * kbf) * NR + r) << 4;
             if (fr < nfr) piece[it] = *reinterpret_cast<const u32x4 *>(a.bits + (size_t)(v_lo + fr) * DW + 4 * kbf);
@@ -215,19 +221,53 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
         for (int q = 0; q < 4; ++q) {
             const unsigned x = piece[it][q];
             const u32x4 o = {(x << 1) & 0x22222222u, x & 0x22222222u, (x >> 1) & 0x22222222u, (x >> 2) & 0x22222222u};
-            *reinterpret_cast<u32x4 *>(lds + dst[it] + ((q * NR) << 4)) = o;
+            if (FULL || 4 * cpiece[it] + q < CH) *reinterpret_cast<u32x4 *>(lds + dst[it] + ((q * NR) << 4)) = o;
         }
     }
     f32x4 acc[MX_NT];
 #pragma unroll
     for (int j = 0; j < MX_NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     MX_STAMP(1)
+    if (a.packed) {
+        // Leftover array: the staging above left slot r = the row's own (at most eight) leftover features in the chunk order,
+        // i.e. in the low byte of each of its four dwords.  A pair whose first frame is row b reads slot b + k0 for the tap
+        // rows 2 (k0 .. k0 + 3) + parity, so slot r has to hold the leftovers of rows r .. r + 3: the chunk expansion of the
+        // word lo(r) | lo(r+1) << 8 | lo(r+2) << 16 | lo(r+3) << 24, which is dword by dword the OR of the four rows' slots
+        // shifted by 0 / 8 / 16 / 24 bits (a nibble is four bits, a feature's index moves by 8 per row).  In place: everybody
+        // reads, barrier, everybody writes.  Rows past the staged ones hold whatever was there: their weights are zero and
+        // every nibble pattern is a finite fp4 value.
+        __syncthreads();
+        u32x4 o[5];
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {   // (2 * nrows <= 2 * NR <= 2560 slots)
+            const int idx = tid + it * (MX_WAVES * 64);
+            const int plane = idx >= nrows, r = idx - plane * nrows;
+            o[it] = u32x4{0, 0, 0, 0};
+            if (it * (MX_WAVES * 64) >= 2 * nrows) break;   // (wave-uniform: the rounds that have no slot at all)
+            if (idx < 2 * nrows) {
+                const unsigned char *slot = lds + (((plane * CH + nfull) * NR + r) << 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const u32x4 x = *reinterpret_cast<const u32x4 *>(slot + 16 * t);
+                    o[it] |= (x & 0xffu) << (8 * t);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const int idx = tid + it * (MX_WAVES * 64);
+            const int plane = idx >= nrows, r = idx - plane * nrows;
+            if (it * (MX_WAVES * 64) >= 2 * nrows) break;
+            if (idx < 2 * nrows) *reinterpret_cast<u32x4 *>(lds + (((plane * CH + nfull) * NR + r) << 4)) = o[it];
+        }
+    }
     __syncthreads();
     MX_STAMP(2)
-    // per-lane LDS offset of (tile j, row lane & 15), the lane's K-quarter folded in
+    // per-lane LDS offset of (tile j, pair lane & 15): the pair's first frame row
     int tb[MX_NT];
 #pragma unroll
-    for (int j = 0; j < MX_NT; ++j) tb[j] = (g_row[j * 16 + (lane & 15)] + NR * (lane >> 4)) << 4;
+    for (int j = 0; j < MX_NT; ++j) tb[j] = g_row[j * 16 + (lane & 15)] << 4;
 #ifdef MX_PRIO
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
@@ -237,12 +277,10 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
     //      in LDS while it works on this one: the two waves of a SIMD only fill the matrix pipe together (one wave alone
     //      issues at half its rate, tools/ubench/mx_rate.hip), and with fixed shares the wave that loses the issue
     //      arbitration is left to finish alone ----
-    auto koff_of = [&](int kb) {
-        const int rho = kb / KBF, kbf = kb - rho * KBF;
-        return ((rho >> 1) + NR * ((rho & 1) * CH + 4 * kbf)) << 4;
-    };
+    // the chunk that feeds this lane's K-quarter of a K-block (any chunk of any tap row: a K-block is four of them)
+    auto kq_of = [&](int kb) { return a.kq[(kb < a.NKB ? kb : a.NKB - 1) * 4 + (lane >> 4)]; };
     i32x4 A[MX_DEPTH];
-    int koff = koff_of(wave);
+    int koff = kq_of(wave), koff_1 = kq_of(wave + MX_WAVES);   // this K-block's and the next one's (requested two K-blocks ahead)
 #pragma unroll
     for (int j = 0; j < MX_DEPTH; ++j) A[j] = *reinterpret_cast<const i32x4 *>(lds + tb[j] + koff);
     // Three register sets for the B fragments in rotation (the loop body exists three times so that no set is ever copied):
@@ -261,7 +299,8 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
         if (lane == 0) kb_3 = (int)__hip_atomic_fetch_add(next_kb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
         const bool more = kb_1 < a.NKB;
-        const int koff_n = more ? koff_of(kb_1) : koff;
+        const int koff_n = koff_1;
+        const int koff_2 = kq_of(kb_2);
         const int kb_ld = kb_2 < a.NKB ? kb_2 : a.NKB - 1;
         i32x8 B[3];
 #pragma unroll
@@ -313,6 +352,7 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
 #endif
         }
         koff = koff_n;
+        koff_1 = koff_2;
         kb_1 = kb_2;
         kb_2 = __builtin_amdgcn_readfirstlane(kb_3);
         return more;
@@ -450,6 +490,7 @@ void tsr_mx_bank_free(tsr_bank *bank)
     (void)hipSetDevice(bank->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(mb->d_B);
+    (void)hipFree(mb->d_kq);
     (void)hipFree(mb->d_cols);
     delete mb;
     bank->mx = nullptr;
@@ -482,15 +523,33 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
     }
     int Lmin = bank->L[0];
     for (int m = 0; m < M; ++m) Lmin = std::min(Lmin, bank->L[m]);
-    const int ROWS = bank->Lmax + 1, NKB = ROWS * KBF;
-    const int NR = MX_IMAGE / (128 * KBF) / 16 * 16;   // rows per column array: a multiple of 16 (conflict-free fragment reads)
-    if (ROWS + 34 > 2 * NR) {   // (a tile of one long utterance spans 32 + ROWS frames)
+    const int ROWS = bank->Lmax + 1;
+    // Chunks (32 features of one frame = 16 bytes of nibbles): a row has nfull full ones and, for D % 32 != 0, one that is
+    // partly filled.  Up to eight leftover features are not worth a chunk per tap row: the leftovers of FOUR tap rows of one
+    // frame parity (rho, rho + 2, rho + 4, rho + 6) share a chunk (D = 360: 33 x 11 + 9 = 372 chunks = 93 K-blocks instead of
+    // 33 x 12 = 396 = 99 -- 6 % less matrix work, weight stream and fragment reads).  A K-block is any four chunks.
+    const int nfull = (int)(D / 32), lo = (int)(D % 32);
+    const int packed = lo >= 1 && lo <= 8;
+    const int CH = nfull + (lo ? 1 : 0);                       // chunk arrays per frame parity in the LDS image
+    const int NR = MX_IMAGE / (32 * CH) / 16 * 16;             // rows per array: a multiple of 16 (conflict-free fragment reads)
+    struct ChunkRef { int plane, c, rho, k0; };                // c < nfull: features 32 c .. of tap row rho; c == nfull && packed: leftovers of
+    std::vector<ChunkRef> refs;                                // the tap rows plane + 2 (k0 .. k0 + 3); c == nfull && !packed: the partly filled chunk
+    for (int plane = 0; plane < 2; ++plane) {
+        for (int rho = plane; rho < ROWS; rho += 2)
+            for (int c = 0; c < (packed ? nfull : CH); ++c) refs.push_back(ChunkRef{plane, c, rho, 0});
+        if (packed)
+            for (int k0 = 0; plane + 2 * k0 < ROWS; k0 += 4) refs.push_back(ChunkRef{plane, nfull, -1, k0});
+    }
+    const int NKB = (int)((refs.size() + 3) / 4);
+    while ((int)refs.size() < 4 * NKB) refs.push_back(ChunkRef{0, 0, -2, 0});   // filler: zero weights, any valid chunk
+    if (ROWS + 34 > 2 * NR || NKB < 3 * MX_WAVES) {   // (a tile of one long utterance spans 32 + ROWS frames; every wave starts with three K-blocks)
         bank->mx_unsupported = true;
         return TSR_ERR_UNSUPPORTED;
     }
     TSR_HIP(hipSetDevice(ctx->device));
     MxBank *mb = new MxBank;
     mb->KBF = KBF; mb->ROWS = ROWS; mb->NKB = NKB; mb->NR = NR; mb->Lmin = Lmin; mb->Lmax = bank->Lmax;
+    mb->CH = CH; mb->nfull = nfull; mb->packed = packed;
     std::vector<MxCol> cols(16);
     std::vector<double> scale(M);
     std::vector<int64_t> woff(M + 1, 0);
@@ -511,18 +570,32 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
         else cols[n] = MxCol{0.0f, -INFINITY, 1 << 30, 0x7ffffffe};
     }
     std::vector<unsigned char> Bf((size_t)NKB * 3 * 1536, 0);
+    std::vector<int32_t> kq((size_t)NKB * 4);
     for (int kb = 0; kb < NKB; ++kb) {
-        const int rho = kb / KBF, kbf = kb % KBF;
+        for (int q = 0; q < 4; ++q) {
+            const ChunkRef &cr = refs[(size_t)kb * 4 + q];
+            const int row = cr.rho >= 0 ? (cr.rho >> 1) : cr.rho == -1 ? cr.k0 : 0;   // rows behind the pair's first frame row
+            kq[(size_t)kb * 4 + q] = ((cr.plane * CH + cr.c) * NR + row) << 4;
+        }
         for (int lane = 0; lane < 64; ++lane) {
             const int n = lane & 15, q = lane >> 4, s = n >> 3, m = n & 7;
+            const ChunkRef &cr = refs[(size_t)kb * 4 + q];
             uint32_t str[3][6] = {{0}};
-            const int tau = rho - s;
-            if (m < M && tau >= 0 && tau < bank->L[m]) {
-                const float *Wrow = bank->W_cat.data() + woff[m] + (int64_t)tau * D;
+            if (m < M && cr.rho != -2) {
                 for (int e = 0; e < 32; ++e) {
-                    const int64_t f = 128 * kbf + 32 * q + 4 * (e & 7) + (e >> 3);   // element 8 k + j = feature 4 j + k of the chunk
-                    if (f >= D) continue;
-                    const long v = lrint((double)Wrow[f] * scale[m]);
+                    int tau;
+                    int64_t f;
+                    if (cr.rho >= 0) {          // element 8 k + j = feature 4 j + k of the chunk (the order the bit rows expand to)
+                        tau = cr.rho - s;
+                        f = 32 * (int64_t)cr.c + 4 * (e & 7) + (e >> 3);
+                    } else {                    // leftover chunk: bit v = 4 j + k of lo(r) | lo(r+1) << 8 | ...: tap row k0 + (v >> 3), feature v & 7
+                        const int v = 4 * (e & 7) + (e >> 3);
+                        tau = cr.plane + 2 * (cr.k0 + (v >> 3)) - s;
+                        f = 32 * (int64_t)nfull + (v & 7);
+                    }
+                    if (f >= D || tau < 0 || tau >= bank->L[m]) continue;
+                    const float w = bank->W_cat[(size_t)(woff[m] + (int64_t)tau * D + f)];
+                    const long v = lrint((double)w * scale[m]);
                     const long l2 = (v + 128) >> 8;              // (arithmetic shift: floor) -16 .. 16
                     const long r = v - 256 * l2;                 // -128 .. 127
                     const long l1 = (r + 8) >> 4;                // -8 .. 8
@@ -550,6 +623,7 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
     };
     up(reinterpret_cast<void **>(&mb->d_B), Bf.data(), Bf.size());
     up(reinterpret_cast<void **>(&mb->d_cols), cols.data(), cols.size() * sizeof(MxCol));
+    up(reinterpret_cast<void **>(&mb->d_kq), kq.data(), kq.size() * 4);
     if (st == TSR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = TSR_ERR_HIP;
     bank->mx = mb;
     if (st != TSR_OK) {
@@ -686,18 +760,29 @@ int tsr_launch_mx_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, float
     TSR_TRY(mx_corpus_plan(ctx, cp, mb));
     const MxCorpus *mc = mxc(cp);
     if (mc->n_wg == 0) return TSR_OK;
-    const void *kern = mb->KBF == 1 ? reinterpret_cast<const void *>(mx_bank_kernel<1>) : mb->KBF == 2 ? reinterpret_cast<const void *>(mx_bank_kernel<2>)
-                     : mb->KBF == 3 ? reinterpret_cast<const void *>(mx_bank_kernel<3>) : reinterpret_cast<const void *>(mx_bank_kernel<4>);
-    static bool attr_set[MX_MAX_KBF + 1] = {false, false, false, false, false};
-    if (!attr_set[mb->KBF]) {
+    const bool full = mb->CH == 4 * mb->KBF;
+    const void *kern = nullptr;
+    switch (mb->KBF * 2 + (full ? 1 : 0)) {
+    case 2: kern = reinterpret_cast<const void *>(mx_bank_kernel<1, false>); break;
+    case 3: kern = reinterpret_cast<const void *>(mx_bank_kernel<1, true>); break;
+    case 4: kern = reinterpret_cast<const void *>(mx_bank_kernel<2, false>); break;
+    case 5: kern = reinterpret_cast<const void *>(mx_bank_kernel<2, true>); break;
+    case 6: kern = reinterpret_cast<const void *>(mx_bank_kernel<3, false>); break;
+    case 7: kern = reinterpret_cast<const void *>(mx_bank_kernel<3, true>); break;
+    case 8: kern = reinterpret_cast<const void *>(mx_bank_kernel<4, false>); break;
+    default: kern = reinterpret_cast<const void *>(mx_bank_kernel<4, true>); break;
+    }
+    static bool attr_set[2 * MX_MAX_KBF + 2] = {false};
+    if (!attr_set[mb->KBF * 2 + (full ? 1 : 0)]) {
         TSR_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS));
-        attr_set[mb->KBF] = true;
+        attr_set[mb->KBF * 2 + (full ? 1 : 0)] = true;
     }
     MxArgs a;
     a.bits = mc->d_bits; a.B = mb->d_B; a.groups = mc->d_groups; a.wg = mc->d_wg; a.cols = mb->d_cols;
     a.scores = d_scores; a.ids = d_ids;
+    a.kq = mb->d_kq; a.CH = mb->CH; a.nfull = mb->nfull; a.packed = mb->packed;
     a.n_groups = mc->n_groups; a.NKB = mb->NKB; a.KBF = mb->KBF; a.NR = mb->NR; a.Lmin = mb->Lmin; a.idmax = mb->idmax; a.cmax = mb->cmax;
-    TSR_REQUIRE((size_t)128 * mb->KBF * mb->NR <= (size_t)MX_IMAGE && (size_t)MX_NT * 7 * 1024 <= (size_t)MX_IMAGE, "TSR_MX: LDS image too large");
+    TSR_REQUIRE((size_t)32 * mb->CH * mb->NR <= (size_t)MX_IMAGE && (size_t)MX_NT * 7 * 1024 <= (size_t)MX_IMAGE, "TSR_MX: LDS image too large");
     const size_t lds = MX_LDS;
     a.dbg = nullptr;
 #ifdef TSR_STAMP
