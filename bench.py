@@ -366,15 +366,23 @@ def roofline_of(mode, per_launch_s, frames, traffic):
         # (73.2 MB at 8 TB/s = 9.2 us against 31.15 Gflop at 10 PF = 3.1 us).  What the kernel issues is three digit
         # products per algorithmic MAC on 33 tap rows x 384 features for windows of 32 x 360 (x 170/169 start pairs):
         # 9.9 us of matrix work at the spec peak -- the two bounds are level, and both are reported.
-        limbs, kpad, rows = 3, (128 * math.ceil(D / 128)) / D, (CFG["L"] + 1) / CFG["L"]
+        # K as the kernel lays it out (csrc/detect_mx.hip): L + 1 tap rows of D // 32 full chunks, the leftover features of a
+        # row either a chunk of their own or (D % 32 <= 8) one chunk per four tap rows of a frame parity; K-blocks of four chunks
+        rows_n, nfull, lo = CFG["L"] + 1, D // 32, D % 32
+        if 1 <= lo <= 8:
+            chunks = rows_n * nfull + sum(math.ceil(len(range(p, rows_n, 2)) / 4) for p in (0, 1))
+        else:
+            chunks = rows_n * (nfull + (1 if lo else 0))
+        limbs, kpad, rows = 3, 128 * math.ceil(chunks / 4) / (rows_n * D), rows_n / CFG["L"]
         pairs = 2 * math.ceil((CFG["T"] - CFG["L"] + 1) / 2) / (CFG["T"] - CFG["L"] + 1)
         issued = tops * limbs * kpad * rows * pairs
         return dict(hbm, bound="hbm", traffic=traffic, kernel_ms_per_launch=per_launch_s * 1e3, alg_flops_per_launch=ALG_FLOPS,
                     mfma={"achieved": tops, "peak": MFMA_FP6_PEAK_TOPS, "unit": "TFLOP/s", "frac": tops / MFMA_FP6_PEAK_TOPS,
                           "issued": {"digit_macs_per_alg_mac": limbs, "k_pad": kpad, "tap_rows": rows, "start_pairs": pairs,
                                      "fp6_tops": issued, "frac_of_peak": issued / MFMA_FP6_PEAK_TOPS, "kernel": "mx_bank_kernel",
-                                     "what": "fp6 x fp4 ops the kernel issues = algorithmic x 3 digits x K padding (%d/%d) x tap rows "
-                                             "(%d/%d) x start pairs" % (128 * math.ceil(D / 128), D, CFG["L"] + 1, CFG["L"])},
+                                     "what": "fp6 x fp4 ops the kernel issues = algorithmic x 3 digits x K padding (%d K-elements for %d "
+                                             "tap rows x %d features) x tap rows (%d/%d) x start pairs"
+                                             % (128 * math.ceil(chunks / 4), rows_n, D, rows_n, CFG["L"])},
                           "peak_note": "dense fp6 / fp4 MFMA = 4x the ~2.5 PF bf16 dense peak (MI355X_MICROARCH.md)"},
                     bound_note="algorithmic intensity 425 flop/B is below the fp6 machine balance of 1250 op/B: HBM is the "
                                "binding roofline of this path at this precision; `achieved` = algorithmic bytes (366 B per "

@@ -83,7 +83,7 @@ enum { TSR_EXACT = 0, TSR_FAST = 1, TSR_W24 = 2, TSR_BF16 = 4, TSR_MX = 8 };
  *              (csrc/detect_mx.hip) and the fastest path for a bank of up to eight templates on rows of up to 512
  *              features (BASELINE config 2); |error| <= 2^-13 * max|W_m| per SET tap in the worst case, unbiased --
  *              observed 2e-5 relative on config 2 (scores of order 4 * 10^3), i.e. eight times TSR_FAST's figure and a
- *              fifth of the 1e-4 bar.  Max mode only (scores + ids); other banks, all-scores passes and filters of at
+ *              fifth of the 1e-4 bar.  Max mode (scores + ids) and all-scores passes; other banks and filters of at
  *              most 4096 taps are served as plain TSR_FAST.  Stands alone beside TSR_FAST (not with TSR_W24 / TSR_BF16). */
 
 typedef struct tsr_ctx tsr_ctx;       /* device + stream + scratch                 */

@@ -63,9 +63,11 @@ struct MxArgs {
     const MxCol *cols;        // [16]
     float *scores;
     int32_t *ids;
+    float *all;               // all-scores pass: [M][P] per-template scores instead of the maximum (scores / ids unused)
+    int64_t P;
     const int32_t *kq;        // [NKB][4] LDS byte offset of the chunk that feeds K-quarter q of K-block kb (frame row 0 of a pair)
     int n_groups, NKB, KBF, NR, Lmin, idmax;
-    int CH, nfull, packed;    // chunk arrays per frame parity; full 32-feature chunks of a row; leftover features of four tap rows share a chunk
+    int CH, nfull, packed, M;    // chunk arrays per frame parity; full 32-feature chunks of a row; leftover features of four tap rows share a chunk
     float cmax;
     unsigned long long *dbg;  // -DTSR_STAMP builds only: [workgroup][wave][16] s_memtime stamps
 };
@@ -119,10 +121,19 @@ __global__ void mx_pack_bits_kernel(const uint8_t *feats, int Dp, const int64_t 
     const int64_t t = v - voff[lo], T = off[lo + 1] - off[lo];
     uint32_t word = 0;
     if (t < T) {
-        const uint8_t *row = feats + (off[lo] + t) * (int64_t)Dp;
-        for (int k = 0; k < 32; ++k) {
-            const int d = 32 * w + k;
-            if (d < Dp && row[d]) word |= 1u << k;
+        // resident bytes are 0 / 1: eight of them become eight bits by one multiply (byte i lands on bit 56 + i, no two
+        // partial products share a bit)
+        const uint8_t *row = feats + (off[lo] + t) * (int64_t)Dp + 32 * w;
+        const int nb = Dp - 32 * w;   // bytes this dword covers inside the row (a multiple of 16, at most 32)
+        if (nb > 0) {
+            const uint4 x0 = *reinterpret_cast<const uint4 *>(row);
+            uint4 x1 = make_uint4(0, 0, 0, 0);
+            if (nb > 16) x1 = *reinterpret_cast<const uint4 *>(row + 16);
+            auto pack8 = [](unsigned lo32, unsigned hi32) {
+                const unsigned long long x = ((unsigned long long)hi32 << 32) | lo32;
+                return (uint32_t)((x * 0x0102040810204080ull) >> 56);
+            };
+            word = pack8(x0.x, x0.y) | (pack8(x0.z, x0.w) << 8) | (pack8(x1.x, x1.y) << 16) | (pack8(x1.z, x1.w) << 24);
         }
     }
     bits[idx] = word;
@@ -392,6 +403,7 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
 #pragma unroll
     for (int w = 1; w < MX_WAVES; ++w) {
         if (wave == w) {
+            asm volatile("" ::: "memory");   // (keeps this a branch: as selects it is 84 conditional moves for every wave)
             own[0] = acc[w];
             own[1] = acc[w + 8];
             if (w + 16 < MX_NT) own[2] = acc[w + 16];
@@ -431,6 +443,7 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
         for (int g = 0; g < 4; ++g) {
             const bool valid = s + col[g].L <= grem[u];
             const float val = (valid ? sum[u][g] * col[g].inv_scale : 0.0f) + col[g].c;
+            if (a.all && ok[u] && s < grem[u] && col[g].L < (1 << 30)) a.all[(int64_t)col[g].id * a.P + gp0[u] + s] = val;
             if (g == 0 || val > bv) {
                 bv = val;
                 bm = 4 * h + g;
@@ -442,6 +455,7 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
             bv = ov;
             bm = om;
         }
+        if (a.all) continue;
         if (ok[u] && h == 0 && s < grem[u]) {   // lanes 0..15: the first start of a pair, lanes 32..47: the second
             a.scores[gp0[u] + s] = bv;
             a.ids[gp0[u] + s] = bm;
@@ -457,8 +471,12 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
             todo &= todo - 1;
             const int bp = __builtin_amdgcn_readlane(gp0[u], i), br = __builtin_amdgcn_readlane(grem[u], i);
             for (int t = 2 + lane; t < br; t += 64) {
-                a.scores[bp + t] = a.cmax;
-                a.ids[bp + t] = a.idmax;
+                if (a.all) {
+                    for (int m = 0; m < a.M; ++m) a.all[(int64_t)m * a.P + bp + t] = a.cols[m].c;
+                } else {
+                    a.scores[bp + t] = a.cmax;
+                    a.ids[bp + t] = a.idmax;
+                }
             }
         }
     }
@@ -746,11 +764,12 @@ static int mx_corpus_plan(tsr_ctx *ctx, tsr_corpus *cp, const MxBank *mb)
     return TSR_OK;
 }
 
-// TSR_FAST | TSR_MX, max mode.  TSR_ERR_UNSUPPORTED when the bank or the corpus does not fit (the caller then takes
+// TSR_FAST | TSR_MX: the maximum over the templates with its id, or (d_all) every template's scores [M][P].
+// TSR_ERR_UNSUPPORTED when the bank or the corpus does not fit (the caller then takes
 // the int8 kernels).
-int tsr_launch_mx_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, float *d_scores, int32_t *d_ids)
+int tsr_launch_mx_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, float *d_scores, int32_t *d_ids, float *d_all)
 {
-    if (!d_scores || !d_ids) return TSR_ERR_UNSUPPORTED;
+    if (!d_all && (!d_scores || !d_ids)) return TSR_ERR_UNSUPPORTED;
     tsr_bank *wb = const_cast<tsr_bank *>(bank);
     TSR_TRY(mx_bank_build(ctx, wb));
     const MxBank *mb = mxb(bank);
@@ -779,7 +798,7 @@ int tsr_launch_mx_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, float
     }
     MxArgs a;
     a.bits = mc->d_bits; a.B = mb->d_B; a.groups = mc->d_groups; a.wg = mc->d_wg; a.cols = mb->d_cols;
-    a.scores = d_scores; a.ids = d_ids;
+    a.scores = d_scores; a.ids = d_ids; a.all = d_all; a.P = cp->P; a.M = bank->M;
     a.kq = mb->d_kq; a.CH = mb->CH; a.nfull = mb->nfull; a.packed = mb->packed;
     a.n_groups = mc->n_groups; a.NKB = mb->NKB; a.KBF = mb->KBF; a.NR = mb->NR; a.Lmin = mb->Lmin; a.idmax = mb->idmax; a.cmax = mb->cmax;
     TSR_REQUIRE((size_t)32 * mb->CH * mb->NR <= (size_t)MX_IMAGE && (size_t)MX_NT * 7 * 1024 <= (size_t)MX_IMAGE, "TSR_MX: LDS image too large");

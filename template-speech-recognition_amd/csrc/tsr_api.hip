@@ -850,13 +850,13 @@ static int corpus_score_impl(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp,
     TSR_HIP(hipSetDevice(ctx->device));
     if (flags & TSR_MX) {
         // 13-bit weights as three fp6 limbs on the block-scaled matrix instruction (detect_mx.hip): banks of up to eight
-        // templates on rows of up to 512 features, max mode.  Anything else -- and short filters, whose scores of order
-        // one want more than 13 bits -- is served as plain TSR_FAST.
+        // templates on rows of up to 512 features (max mode and all-scores passes).  Anything else -- and short filters,
+        // whose scores of order one want more than 13 bits -- is served as plain TSR_FAST.
         flags &= ~TSR_MX;
         int32_t Lmin = bank->Lmax;
         for (int32_t l : bank->L) Lmin = std::min(Lmin, l);
-        if (!d_all && (int64_t)Lmin * bank->D > TSR_FAST_W24_BELOW_TAPS) {
-            const int sm = tsr_launch_mx_bank(ctx, bank, cp, cp->d_scores, cp->d_ids);
+        if ((int64_t)Lmin * bank->D > TSR_FAST_W24_BELOW_TAPS) {
+            const int sm = tsr_launch_mx_bank(ctx, bank, cp, d_all ? nullptr : cp->d_scores, d_all ? nullptr : cp->d_ids, d_all);
             if (sm == TSR_OK) ctx->last_bank_kernel = TSR_KERNEL_MX;
             if (sm != TSR_ERR_UNSUPPORTED) return sm;
         }

@@ -302,7 +302,7 @@ int tsr_launch_tap2_bank(tsr_ctx *ctx, const tsr_bank *bank, struct tsr_corpus *
 int tsr_launch_fast_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *corpus, int flags,
                          float *d_scores, int32_t *d_ids, float *d_all);
 // detect_mx.hip
-int tsr_launch_mx_bank(tsr_ctx *ctx, const tsr_bank *bank, struct tsr_corpus *cp, float *d_scores, int32_t *d_ids);
+int tsr_launch_mx_bank(tsr_ctx *ctx, const tsr_bank *bank, struct tsr_corpus *cp, float *d_scores, int32_t *d_ids, float *d_all);
 void tsr_mx_bank_free(tsr_bank *bank);
 void tsr_mx_corpus_free(struct tsr_corpus *cp);
 // parts.hip

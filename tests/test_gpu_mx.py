@@ -163,8 +163,8 @@ def test_mx_long_utterance(tsr_hip, oracle):
 
 
 def test_mx_requests_outside_its_envelope_are_served_as_fast(tsr_hip, oracle):
-    """More than eight templates, rows wider than 512 features, all-scores passes and short filters fall to TSR_FAST's
-    int8 kernels: same results as plain TSR_FAST, bit for bit."""
+    """More than eight templates, rows wider than 512 features and short filters fall to TSR_FAST's int8 kernels: same
+    results as plain TSR_FAST, bit for bit."""
     from tsr_hip import synth
     for shape in (dict(N=3, T=[90, 140, 60], F=45, E=8, M=9, L=32), dict(N=2, T=[70, 90], F=80, E=8, M=4, L=32),
                   dict(N=3, T=[40, 50, 30], F=6, E=5, M=3, L=9)):
@@ -180,8 +180,35 @@ def test_mx_requests_outside_its_envelope_are_served_as_fast(tsr_hip, oracle):
     P = int(c["offsets"][-1])
     bank = tsr_hip.Bank(c["bank"])
     dc = tsr_hip.Corpus(c["feats"].reshape(P, -1), c["offsets"])
-    assert np.array_equal(dc.score_all(bank, tsr_hip.TSR_FAST | tsr_hip.TSR_MX), dc.score_all(bank, tsr_hip.TSR_FAST))
     with pytest.raises(ValueError):
         dc.score(bank, tsr_hip.TSR_FAST | tsr_hip.TSR_MX | tsr_hip.TSR_W24)
+    dc.close()
+    bank.close()
+
+
+@pytest.mark.parametrize("shape", [
+    dict(N=7, T=[200, 199, 33, 32, 31, 5, 64], F=45, E=8, M=8, L=32),
+    dict(N=5, T=[90, 0, 61, 1, 47], F=45, E=8, M=5, L=[20, 24, 28, 32, 36]),
+    dict(N=40, T=70, F=45, E=8, M=7, L=[32, 32, 33, 34, 35, 36, 37]),
+], ids=["odd_T", "ragged_L", "short_utts"])
+def test_mx_all_scores_pass(tsr_hip, oracle, shape):
+    """The all-scores pass of the MX kernel: every template's score at every frame (tail frames: 0 + c_m) against the
+    emulation, its maximum equal to the fused pass bit for bit, and within the bar of TSR_EXACT's all-scores pass."""
+    from tsr_hip import synth
+    c = synth.corpus(78, **shape)
+    P = int(c["offsets"][-1])
+    f2 = c["feats"].reshape(P, -1)
+    bank = tsr_hip.Bank(c["bank"])
+    dc = tsr_hip.Corpus(f2, c["offsets"])
+    allm = dc.score_all(bank, tsr_hip.TSR_FAST | tsr_hip.TSR_MX)
+    assert tsr_hip.default_ctx().get_option(tsr_hip.TSR_INFO_LAST_BANK_KERNEL) == tsr_hip.TSR_KERNEL_MX
+    dc.score(bank, tsr_hip.TSR_FAST | tsr_hip.TSR_MX)
+    s, a = dc.download()
+    es, ea, vals, slack = _emulate(f2, c["offsets"], c["bank"])
+    assert allm.shape == vals.shape
+    assert np.all(np.abs(allm - vals) <= slack[None, :] + 1e-30)
+    assert np.array_equal(allm.max(0), s)
+    alle = dc.score_all(bank, tsr_hip.TSR_EXACT)
+    assert rel_err(allm, alle) <= TOL
     dc.close()
     bank.close()
