@@ -67,7 +67,8 @@ struct MxArgs {
     int64_t P;
     const int32_t *kq;        // [NKB][4] LDS byte offset of the chunk that feeds K-quarter q of K-block kb (frame row 0 of a pair)
     int n_groups, NKB, KBF, NR, Lmin, idmax;
-    int CH, nfull, packed, M;    // chunk arrays per frame parity; full 32-feature chunks of a row; leftover features of four tap rows share a chunk
+    int CH, nfull, packed, M;
+    int slow_cap;             // K-blocks a wave of the slower half (waves 4..7) takes at most    // chunk arrays per frame parity; full 32-feature chunks of a row; leftover features of four tap rows share a chunk
     float cmax;
     unsigned long long *dbg;  // -DTSR_STAMP builds only: [workgroup][wave][16] s_memtime stamps
 };
@@ -301,13 +302,21 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
     // K-block ahead, so that nobody waits for the atomic's return (a wave that waits issues nothing, and its SIMD
     // partner alone runs at half rate).
     int kb_1 = wave + MX_WAVES, kb_2 = wave + 2 * MX_WAVES;   // the two K-blocks after this one
+    int taken = 0;
     auto kblock = [&](const i32x4 (&c4)[3], const i32x2 (&c2)[3], i32x4 (&n4)[3], i32x2 (&n2)[3]) -> bool {
         // c: this K-block's fragments; n: the set that is free now and takes those of the K-block after the next
         int kb_3 = 0;
 #if MX_ABL & 8   // development ablation: fixed shares (wave w takes K-blocks w, w + 8, ...)
         kb_3 = kb_2 + MX_WAVES;
 #else
-        if (lane == 0) kb_3 = (int)__hip_atomic_fetch_add(next_kb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // The two waves of a SIMD do not get equal shares of its issue slots (the older one, waves 0..3, wins the
+        // arbitration: tools/ubench/mx_rate.hip), so the younger half needs ~1.4 x as long for a K-block; with K-blocks drawn
+        // two ahead it would still hold two of them when the pool is empty.  It stops drawing after slow_cap K-blocks and
+        // the older half finishes the pool.
+        ++taken;
+        if (lane == 0 && (wave < 4 || taken + 2 < a.slow_cap))
+            kb_3 = (int)__hip_atomic_fetch_add(next_kb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else if (lane == 0) kb_3 = a.NKB;
 #endif
         const bool more = kb_1 < a.NKB;
         const int koff_n = koff_1;
@@ -798,6 +807,10 @@ int tsr_launch_mx_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, float
     }
     MxArgs a;
     a.bits = mc->d_bits; a.B = mb->d_B; a.groups = mc->d_groups; a.wg = mc->d_wg; a.cols = mb->d_cols;
+    {   // (development override: TSR_MX_SLOWCAP)
+        const char *e = getenv("TSR_MX_SLOWCAP");
+        a.slow_cap = e ? atoi(e) : (mb->NKB * 13 + 63) / 64 / 2 + 1;
+    }
     a.scores = d_scores; a.ids = d_ids; a.all = d_all; a.P = cp->P; a.M = bank->M;
     a.kq = mb->d_kq; a.CH = mb->CH; a.nfull = mb->nfull; a.packed = mb->packed;
     a.n_groups = mc->n_groups; a.NKB = mb->NKB; a.KBF = mb->KBF; a.NR = mb->NR; a.Lmin = mb->Lmin; a.idmax = mb->idmax; a.cmax = mb->cmax;
