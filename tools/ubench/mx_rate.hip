@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <vector>
 using i32x8 = __attribute__((ext_vector_type(8))) int;
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+using i32x2 = __attribute__((ext_vector_type(2))) int;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
@@ -158,6 +160,93 @@ template <int W, int NT> int run_like_t(unsigned long long *dout, float *dsink, 
     return 0;
 }
 
+
+// The K loop of csrc/detect_mx.hip WITH its operand feeds, to price workgroup shapes before building them: W waves per SIMD,
+// NT tiles per wave and K-block; per K-block 3 NT matrix instructions, NT ds_read_b128 (+ one address add each) into a ring
+// seven deep, six global loads of the next K-block's weight fragments (an L2-resident buffer all workgroups share).
+template <int W, int NT>
+__global__ __launch_bounds__(W * 256, W) void loop_fed(int kblocks, unsigned long long *out, float *sink, const unsigned char *wbuf, int wblocks)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 40960 / 16; i += W * 256) reinterpret_cast<i32x4 *>(lds)[i] = i32x4{0x02002000, 0x00020200, 0x20000002, 0x00202000};
+    __syncthreads();
+    int tb[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) tb[j] = ((j * 16 + (lane & 15)) + 640 * (lane >> 4)) << 4;   // column-major image, 640 rows per array
+    i32x4 A[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) A[j] = *reinterpret_cast<const i32x4 *>(lds + tb[j % NT]);
+    const unsigned char *wp = wbuf + (size_t)((wave * 7) % wblocks) * 4608 + lane * 16;
+    i32x4 c4[3], n4[3];
+    i32x2 c2[3], n2[3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        c4[l] = n4[l] = *reinterpret_cast<const i32x4 *>(wp + l * 1536);
+        c2[l] = n2[l] = *reinterpret_cast<const i32x2 *>(wp + l * 1536 + 1024 - lane * 8);
+    }
+    f32x4 acc[NT] = {};
+    unsigned long long t0, r0, t1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
+    for (int kb = 0; kb < kblocks; ++kb) {
+        const int koff = (kb & 15) << 4;
+        const unsigned char *nb = wbuf + (size_t)((kb * 8 + wave) % wblocks) * 4608 + lane * 16;
+        i32x8 B[3];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) B[l] = i32x8{c4[l][0], c4[l][1], c4[l][2], c4[l][3], c2[l][0], c2[l][1], 0, 0};
+        constexpr int NG = (NT + 2) / 3;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g < 6) {
+                if (g & 1) n2[g / 2] = *reinterpret_cast<const i32x2 *>(nb + (g / 2) * 1536 + 1024 - lane * 8);
+                else n4[g / 2] = *reinterpret_cast<const i32x4 *>(nb + (g / 2) * 1536);
+            }
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if (3 * g + u < NT) {
+                        const i32x4 x = A[(3 * g + u) % 7];
+                        acc[3 * g + u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(B[l], i32x8{x[0], x[1], x[2], x[3], 0, 0, 0, 0}, acc[3 * g + u], 2, 4, 0,
+                                                                                          l == 0 ? (int)0x82828282u : l == 1 ? (int)0x86868686u : (int)0x8a8a8a8au, 0, 0x7f7f7f7f);
+                    }
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (3 * g + u < NT) A[(3 * g + u) % 7] = *reinterpret_cast<const i32x4 *>(lds + tb[(3 * g + u + 7) % NT] + koff);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int l = 0; l < 3; ++l) { c4[l] = n4[l]; c2[l] = n2[l]; }
+    }
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
+    float x = 0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) x += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    if (x == 1.2345f) sink[0] = x;
+    if (lane == 0) {
+        out[(blockIdx.x * 16 + wave) * 2] = t1 - t0;
+        out[(blockIdx.x * 16 + wave) * 2 + 1] = r1 - r0;
+    }
+}
+
+template <int W, int NT> int run_fed(unsigned long long *dout, float *dsink, const unsigned char *wbuf, int kblocks)
+{
+    CK(hipMemset(dout, 0, 256 * 16 * 16));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(loop_fed<W, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 40960));
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((loop_fed<W, NT>), dim3(256), dim3(W * 256), 40960, 0, kblocks, dout, dsink, wbuf, 93);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h(256 * 16 * 2);
+    CK(hipMemcpy(h.data(), dout, h.size() * 8, hipMemcpyDeviceToHost));
+    double cyc = 0, hi = 0;
+    int n = 0;
+    for (int i = 0; i < 256 * 16; ++i)
+        if (h[2 * i]) { cyc += h[2 * i]; hi = hi > (double)h[2 * i] ? hi : (double)h[2 * i]; ++n; }
+    const double mf = kblocks * 3.0 * NT;
+    printf("fed loop, %d wave(s) per SIMD x %d tiles: mean %.2f cycles per instruction per wave, the slowest wave %.2f => the job ends at %.2f per SIMD\n", W, NT,
+           cyc / n / mf, hi / mf, hi / mf / W);
+    return 0;
+}
+
 template <int W, int S, int D> int run(unsigned long long *dout, float *dsink, const i32x8 *da, const i32x8 *db)
 {
     const int steps = 2000;
@@ -223,6 +312,15 @@ int main()
         printf("operand sets -- all zero:\n");
         CK(hipMemset(da2, 0, a2.size() * 4)); CK(hipMemset(db2, 0, b2.size() * 4));
         run_like<2, 21>(dout, dsink, (i32x8 *)da2, (i32x8 *)db2);
+    }
+    {   // workgroup shapes with the operand feeds: total matrix work per SIMD is the same (W x NT x K-blocks constant)
+        unsigned char *wbuf;
+        CK(hipMalloc(&wbuf, 93 * 4608));
+        CK(hipMemset(wbuf, 0x11, 93 * 4608));
+        run_fed<2, 21>(dout, dsink, wbuf, 24);    // 8 waves: K split 8 ways, all 21 tiles (the committed kernel)
+        run_fed<3, 11>(dout, dsink, wbuf, 31);    // 12 waves: K split 6 ways x 2 tile halves
+        run_fed<3, 7>(dout, dsink, wbuf, 48);     // 12 waves: K split 4 ways x 3 tile thirds
+        run_fed<4, 6>(dout, dsink, wbuf, 42);     // 16 waves: K split 4 ways x 4 tile quarters (5.25 tiles)
     }
     run<1, 1, 0>(dout, dsink, (i32x8 *)da, (i32x8 *)db);
     run<1, 1, 1>(dout, dsink, (i32x8 *)da, (i32x8 *)db);
