@@ -79,8 +79,9 @@ def launch_ranks(n, argv):
 
     def relay():
         for line in procs[0].stdout:      # rank 0 prints the one JSON line; ends when rank 0's stdout closes
-            sys.stdout.write(line)
-            sys.stdout.flush()
+            out = sys.stdout if line.lstrip().startswith("{") else sys.stderr   # (libraries' banners do not belong on stdout)
+            out.write(line)
+            out.flush()
 
     reader = threading.Thread(target=relay, daemon=True)
     reader.start()
@@ -509,6 +510,11 @@ def main():
             return tdist.max_over_ranks(group, 0.0 if flag else 1.0)[0] == 0.0
 
         err = ""
+        # RCCL prints a version banner on stdout when a communicator is created: stdout carries the one JSON line and nothing
+        # else, so file descriptor 1 points at stderr while the library initialises and broadcasts
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         try:
             ctx.dist_init(tdist.exchange_unique_id(group, tsr_hip.unique_id), world, rank)
         except tsr_hip.TsrError as e:
@@ -521,6 +527,9 @@ def main():
             except tsr_hip.TsrError as e:
                 err = str(e)
             rccl = all_ok(not err)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
         if rccl:
             bank_bcast = "rccl"
         else:

@@ -800,11 +800,8 @@ int tsr_launch_mx_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, float
     case 8: kern = reinterpret_cast<const void *>(mx_bank_kernel<4, false>); break;
     default: kern = reinterpret_cast<const void *>(mx_bank_kernel<4, true>); break;
     }
-    static bool attr_set[2 * MX_MAX_KBF + 2] = {false};
-    if (!attr_set[mb->KBF * 2 + (full ? 1 : 0)]) {
-        TSR_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS));
-        attr_set[mb->KBF * 2 + (full ? 1 : 0)] = true;
-    }
+    // (per launch: the attribute belongs to the function on the CURRENT device, and a process may hold several contexts)
+    TSR_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS));
     MxArgs a;
     a.bits = mc->d_bits; a.B = mb->d_B; a.groups = mc->d_groups; a.wg = mc->d_wg; a.cols = mb->d_cols;
     {   // (development override: TSR_MX_SLOWCAP)
