@@ -68,7 +68,9 @@ struct MxArgs {
     const int32_t *kq;        // [NKB][4] LDS byte offset of the chunk that feeds K-quarter q of K-block kb (frame row 0 of a pair)
     int n_groups, NKB, KBF, NR, Lmin, idmax;
     int CH, nfull, packed, M;
-    int slow_cap;             // K-blocks a wave of the slower half (waves 4..7) takes at most    // chunk arrays per frame parity; full 32-feature chunks of a row; leftover features of four tap rows share a chunk
+    int slow_cap;             // K-blocks a wave of the slower half (waves 4..7) takes at most
+    int n_phase, DWr;         // feature phases (rows wider than 512 features: one staging + K loop per phase, one accumulator set); dwords per bit row
+    long long bits_phase, B_phase;   // dwords / bytes from one phase's bit rows / fragments to the next    // chunk arrays per frame parity; full 32-feature chunks of a row; leftover features of four tap rows share a chunk
     float cmax;
     unsigned long long *dbg;  // -DTSR_STAMP builds only: [workgroup][wave][16] s_memtime stamps
 };
@@ -87,7 +89,7 @@ struct MxArgs {
 #endif
 
 struct MxBank {
-    int KBF = 0, ROWS = 0, NKB = 0, NR = 0, Lmin = 0, Lmax = 0, idmax = 0, CH = 0, nfull = 0, packed = 0;
+    int KBF = 0, ROWS = 0, NKB = 0, NR = 0, Lmin = 0, Lmax = 0, idmax = 0, CH = 0, nfull = 0, packed = 0, n_phase = 1, pw = 0;
     int32_t *d_kq = nullptr;
     float cmax = 0;
     unsigned char *d_B = nullptr;
@@ -96,7 +98,9 @@ struct MxBank {
 
 struct MxCorpus {   // derived forms of a corpus: bit rows (once), the tile plan of one (Lmin, ROWS, NR)
     uint32_t *d_bits = nullptr;
-    int DW = 0;
+    const uint32_t *ext_bits = nullptr;   // the corpus' own bit form (wide rows), not owned
+    int DW = 0, DWr = 0;
+    long long bits_phase = 0;
     int64_t Pv = 0, rows_alloc = 0;
     std::vector<int64_t> voff;
     int plan_Lmin = -1, plan_ROWS = -1, plan_NR = -1;
@@ -150,11 +154,11 @@ constexpr int MX_DEPTH = 7;                       // A fragments in flight per w
 static_assert(MX_NT % MX_DEPTH == 0 && MX_NT % 3 == 0, "the fragment ring must line up across K-blocks: tile j lives in A[j % MX_DEPTH]");
 
 // FULL: the row has exactly 4 KBF chunk arrays (every 16-byte piece of a bit row fills four of them: no per-chunk checks)
-template <int KBF, bool FULL>
+// PHASES: rows wider than 512 features, staged and multiplied in feature phases (only <3, true, true> is built)
+template <int KBF, bool FULL, bool PHASES = false>
 __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int DW = 4 * KBF;
     const int CH = a.CH, nfull = a.nfull;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -187,9 +191,19 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
         const int gi = tile_beg * 16 + tid;
         if (tid < nt * 16 && gi < a.n_groups) G = a.groups[gi];
     }
+    f32x4 acc[MX_NT];
+#pragma unroll
+    for (int j = 0; j < MX_NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nrows = (nfr + 1) >> 1;
+    // Feature phases: rows of up to 512 features are one phase; wider rows (part corpora: D = 2050 as six phases of 352) go
+    // through staging and K loop once per phase with the SAME accumulators, so that nothing but the final sums is exchanged.
+    const int n_phase = PHASES ? a.n_phase : 1, DWr = PHASES ? a.DWr : 4 * KBF;
+    for (int ph = 0; ph < n_phase; ++ph) {
+    if (ph) __syncthreads();   // (everybody is done with the previous phase's image and K-block counter)
+    const uint32_t *const bits = PHASES ? a.bits + (size_t)ph * a.bits_phase : a.bits;
+    const unsigned char *const Bph = PHASES ? a.B + (size_t)ph * a.B_phase : a.B;
     // frames -> LDS: lane = row of one (parity, K-block-of-the-row) pass, so that a wave's stores are consecutive 16-byte
     // slots; at most 2 * KBF * NR <= 2496 pieces = five per thread
-    const int nrows = (nfr + 1) >> 1;
     u32x4 piece[5];
     int dst[5], cpiece[5];
 #pragma unroll
@@ -203,10 +217,10 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
         cpiece[it] = kbf;
         if (pass < 2 * KBF) {
             dst[it] = ((plane * CH + 4 * kbf) * NR + r) << 4;
-            if (fr < nfr) piece[it] = *reinterpret_cast<const u32x4 *>(a.bits + (size_t)(v_lo + fr) * DW + 4 * kbf);
+            if (fr < nfr) piece[it] = *reinterpret_cast<const u32x4 *>(bits + (size_t)(v_lo + fr) * DWr + 4 * kbf);
         }
     }
-    const unsigned char *bp = a.B + (size_t)wave * (3 * 1536) + lane * 16;
+    const unsigned char *bp = Bph + (size_t)wave * (3 * 1536) + lane * 16;
     i32x4 b4[3];
     i32x2 b2[3];
 #pragma unroll
@@ -215,7 +229,7 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
         b2[l] = *reinterpret_cast<const i32x2 *>(bp + l * 1536 + 1024 - lane * 8);
     }
     if (tid == 0) *next_kb = 3 * MX_WAVES;   // (wave w starts with the K-blocks w, w + 8 and w + 16)
-    if (tid < MX_GROUPS) {
+    if (tid < MX_GROUPS && ph == 0) {
         g_row[tid] = (G.v0 - v_lo) >> 1;
         g_p0[tid] = G.p0;
         g_rem[tid] = G.rem;
@@ -236,9 +250,6 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
             if (FULL || 4 * cpiece[it] + q < CH) *reinterpret_cast<u32x4 *>(lds + dst[it] + ((q * NR) << 4)) = o;
         }
     }
-    f32x4 acc[MX_NT];
-#pragma unroll
-    for (int j = 0; j < MX_NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     MX_STAMP(1)
     if (a.packed) {
         // Leftover array: the staging above left slot r = the row's own (at most eight) leftover features in the chunk order,
@@ -309,6 +320,11 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
 #if MX_ABL & 8   // development ablation: fixed shares (wave w takes K-blocks w, w + 8, ...)
         kb_3 = kb_2 + MX_WAVES;
 #else
+        // Wide rows: fixed shares.  Their sums pass 2^24, where an f32 addition rounds, so the result depends on which wave
+        // added which K-block in which order; with wave w taking K-blocks w, w + 8, ... every launch adds in the same order
+        // and the scores are the same bit for bit from run to run (measured on config 3: no slower than drawing).
+        if constexpr (PHASES) kb_3 = kb_2 + MX_WAVES;
+        else {
         // The two waves of a SIMD do not get equal shares of its issue slots (the older one, waves 0..3, wins the
         // arbitration: tools/ubench/mx_rate.hip), so the younger half needs ~1.4 x as long for a K-block; with K-blocks drawn
         // two ahead it would still hold two of them when the pool is empty.  It stops drawing after slow_cap K-blocks and
@@ -317,6 +333,7 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
         if (lane == 0 && (wave < 4 || taken + 2 < a.slow_cap))
             kb_3 = (int)__hip_atomic_fetch_add(next_kb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else if (lane == 0) kb_3 = a.NKB;
+        }
 #endif
         const bool more = kb_1 < a.NKB;
         const int koff_n = koff_1;
@@ -336,7 +353,7 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
             // (unconditional -- behind the last K-block it re-reads that one -- so that the sets are plain registers, not
             // merges of old and new values)
             if (j / 3 < 6 && !(MX_ABL & 4)) {
-                const unsigned char *nb = a.B + (size_t)kb_ld * (3 * 1536) + lane * 16 + (j / 6) * 1536;
+                const unsigned char *nb = Bph + (size_t)kb_ld * (3 * 1536) + lane * 16 + (j / 6) * 1536;
                 if ((j / 3) & 1) n2[j / 6] = *reinterpret_cast<const i32x2 *>(nb + 1024 - lane * 8);
                 else n4[j / 6] = *reinterpret_cast<const i32x4 *>(nb);
             }
@@ -380,7 +397,7 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
     i32x4 d4[3], e4[3] = {b4[0], b4[1], b4[2]};
     i32x2 d2[3], e2[3] = {b2[0], b2[1], b2[2]};
     {   // the second K-block's fragments (the first one's were requested at the top of the kernel)
-        const unsigned char *nb = a.B + (size_t)(kb_1 < a.NKB ? kb_1 : a.NKB - 1) * (3 * 1536) + lane * 16;
+        const unsigned char *nb = Bph + (size_t)(kb_1 < a.NKB ? kb_1 : a.NKB - 1) * (3 * 1536) + lane * 16;
 #pragma unroll
         for (int l = 0; l < 3; ++l) {
             d4[l] = *reinterpret_cast<const i32x4 *>(nb + l * 1536);
@@ -389,9 +406,7 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
     }
     while (kblock(b4, b2, e4, e2) && kblock(d4, d2, b4, b2) && kblock(e4, e2, d4, d2)) {
     }
-#ifdef MX_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
+    }   // (feature phases)
 
     MX_STAMP(3)
     // ---- the eight partial sums of a tile meet in LDS (the frames are done with): tile j belongs to wave j & 7 ----
@@ -543,8 +558,17 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
     if (bank->mx_unsupported) return TSR_ERR_UNSUPPORTED;
     const int M = bank->M;
     const int64_t D = bank->D;
-    const int KBF = (int)((D + 127) / 128);
-    if (M < 1 || M > 8 || KBF > MX_MAX_KBF) {
+    // Rows of up to 512 features are one phase in this file's own bit rows.  Wider rows (part corpora) go in feature phases
+    // with the geometry of the corpora's resident bit form (tsr_bit_geometry: D = 2050 -> six phases of 11 dwords = 352
+    // features), which the kernel reads as it lies.
+    int n_phase = 1, pw = 0;
+    int64_t Dph = D;
+    if (D > 128 * MX_MAX_KBF) {
+        tsr_bit_geometry(D, &pw, &n_phase);
+        Dph = 32 * (int64_t)pw;
+    }
+    const int KBF = n_phase > 1 ? 3 : (int)((Dph + 127) / 128);   // (phases: always three staged pieces per row, pw <= 12)
+    if (M < 1 || M > 8 || KBF > MX_MAX_KBF || n_phase > 64) {
         bank->mx_unsupported = true;
         return TSR_ERR_UNSUPPORTED;
     }
@@ -555,15 +579,17 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
     // partly filled.  Up to eight leftover features are not worth a chunk per tap row: the leftovers of FOUR tap rows of one
     // frame parity (rho, rho + 2, rho + 4, rho + 6) share a chunk (D = 360: 33 x 11 + 9 = 372 chunks = 93 K-blocks instead of
     // 33 x 12 = 396 = 99 -- 6 % less matrix work, weight stream and fragment reads).  A K-block is any four chunks.
-    const int nfull = (int)(D / 32), lo = (int)(D % 32);
+    const int nfull = (int)(Dph / 32), lo = (int)(Dph % 32);
     const int packed = lo >= 1 && lo <= 8;
-    const int CH = nfull + (lo ? 1 : 0);                       // chunk arrays per frame parity in the LDS image
+    const int CHw = nfull + (lo ? 1 : 0);                      // chunks of a row that carry weights
+    const int CH = n_phase > 1 ? 4 * KBF : CHw;                // chunk arrays per frame parity in the LDS image (phases: four per
+                                                               // staged piece, so that the staging needs no per-chunk checks)
     const int NR = MX_IMAGE / (32 * CH) / 16 * 16;             // rows per array: a multiple of 16 (conflict-free fragment reads)
     struct ChunkRef { int plane, c, rho, k0; };                // c < nfull: features 32 c .. of tap row rho; c == nfull && packed: leftovers of
     std::vector<ChunkRef> refs;                                // the tap rows plane + 2 (k0 .. k0 + 3); c == nfull && !packed: the partly filled chunk
     for (int plane = 0; plane < 2; ++plane) {
         for (int rho = plane; rho < ROWS; rho += 2)
-            for (int c = 0; c < (packed ? nfull : CH); ++c) refs.push_back(ChunkRef{plane, c, rho, 0});
+            for (int c = 0; c < (packed ? nfull : CHw); ++c) refs.push_back(ChunkRef{plane, c, rho, 0});
         if (packed)
             for (int k0 = 0; plane + 2 * k0 < ROWS; k0 += 4) refs.push_back(ChunkRef{plane, nfull, -1, k0});
     }
@@ -576,7 +602,7 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
     TSR_HIP(hipSetDevice(ctx->device));
     MxBank *mb = new MxBank;
     mb->KBF = KBF; mb->ROWS = ROWS; mb->NKB = NKB; mb->NR = NR; mb->Lmin = Lmin; mb->Lmax = bank->Lmax;
-    mb->CH = CH; mb->nfull = nfull; mb->packed = packed;
+    mb->CH = CH; mb->nfull = nfull; mb->packed = packed; mb->n_phase = n_phase; mb->pw = pw;
     std::vector<MxCol> cols(16);
     std::vector<double> scale(M);
     std::vector<int64_t> woff(M + 1, 0);
@@ -596,14 +622,16 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
         if (m < M) cols[n] = MxCol{(float)(1.0 / scale[m]), (float)bank->c[m], bank->L[m], m};
         else cols[n] = MxCol{0.0f, -INFINITY, 1 << 30, 0x7ffffffe};
     }
-    std::vector<unsigned char> Bf((size_t)NKB * 3 * 1536, 0);
+    std::vector<unsigned char> Bf((size_t)n_phase * NKB * 3 * 1536, 0);
     std::vector<int32_t> kq((size_t)NKB * 4);
-    for (int kb = 0; kb < NKB; ++kb) {
+    for (int kb = 0; kb < NKB; ++kb)
         for (int q = 0; q < 4; ++q) {
             const ChunkRef &cr = refs[(size_t)kb * 4 + q];
             const int row = cr.rho >= 0 ? (cr.rho >> 1) : cr.rho == -1 ? cr.k0 : 0;   // rows behind the pair's first frame row
             kq[(size_t)kb * 4 + q] = ((cr.plane * CH + cr.c) * NR + row) << 4;
         }
+    for (int ph = 0; ph < n_phase; ++ph)
+    for (int kb = 0; kb < NKB; ++kb) {
         for (int lane = 0; lane < 64; ++lane) {
             const int n = lane & 15, q = lane >> 4, s = n >> 3, m = n & 7;
             const ChunkRef &cr = refs[(size_t)kb * 4 + q];
@@ -620,6 +648,8 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
                         tau = cr.plane + 2 * (cr.k0 + (v >> 3)) - s;
                         f = 32 * (int64_t)nfull + (v & 7);
                     }
+                    if (f >= Dph) continue;
+                    f += (int64_t)ph * Dph;     // (the phase's features)
                     if (f >= D || tau < 0 || tau >= bank->L[m]) continue;
                     const float w = bank->W_cat[(size_t)(woff[m] + (int64_t)tau * D + f)];
                     const long v = lrint((double)w * scale[m]);
@@ -637,7 +667,7 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
                 }
             }
             for (int l = 0; l < 3; ++l) {
-                unsigned char *dst = Bf.data() + ((size_t)kb * 3 + l) * 1536;
+                unsigned char *dst = Bf.data() + (((size_t)ph * NKB + kb) * 3 + l) * 1536;
                 memcpy(dst + lane * 16, &str[l][0], 16);
                 memcpy(dst + 1024 + lane * 8, &str[l][4], 8);
             }
@@ -662,14 +692,33 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
 }
 
 // Bit rows of the corpus at virtual positions (every utterance starts on an even row), built once.
-static int mx_corpus_bits(tsr_ctx *ctx, tsr_corpus *cp, int KBF)
+static int mx_corpus_bits(tsr_ctx *ctx, tsr_corpus *cp, const MxBank *mb)
 {
+    const int KBF = mb->KBF;
     MxCorpus *mc = mxc(cp);
     if (!mc) {
         mc = new MxCorpus;
         cp->mx = mc;
     }
+    if (mb->n_phase > 1) {
+        // wide rows: the corpus' own resident bit form, read as it lies -- phase-major [phase][frame][pw dwords] -- when its
+        // geometry is the bank's and every utterance has an even number of frames (a pair of starts must begin in the same
+        // frame parity of the LDS image; this file's own bit rows pad odd utterances, the corpus' form cannot)
+        bool even = true;
+        for (int64_t u = 0; u < cp->N; ++u) even = even && ((cp->offsets[(size_t)u + 1] - cp->offsets[(size_t)u]) & 1) == 0;
+        if (!cp->d_bits || cp->bit_pw != mb->pw || cp->bit_nph != mb->n_phase || !even) return TSR_ERR_UNSUPPORTED;
+        mc->ext_bits = reinterpret_cast<const uint32_t *>(cp->d_bits);
+        mc->DWr = cp->bit_pw;
+        mc->bits_phase = (long long)cp->bit_rows * cp->bit_pw;
+        mc->voff.assign(cp->offsets.begin(), cp->offsets.end());
+        mc->Pv = cp->P;
+        mc->rows_alloc = cp->bit_rows;
+        return TSR_OK;
+    }
     const int DW = 4 * KBF;
+    mc->ext_bits = nullptr;
+    mc->DWr = DW;
+    mc->bits_phase = 0;
     if (mc->d_bits && mc->DW == DW) return TSR_OK;
     TSR_TRY(tsr_corpus_need_bytes(ctx, cp));
     if (mc->d_bits) {
@@ -784,13 +833,14 @@ int tsr_launch_mx_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, float
     const MxBank *mb = mxb(bank);
     if (cp->P == 0) return TSR_OK;
     if (cp->P > (int64_t)INT32_MAX - 4096) return TSR_ERR_UNSUPPORTED;
-    TSR_TRY(mx_corpus_bits(ctx, cp, mb->KBF));
+    TSR_TRY(mx_corpus_bits(ctx, cp, mb));
     TSR_TRY(mx_corpus_plan(ctx, cp, mb));
     const MxCorpus *mc = mxc(cp);
     if (mc->n_wg == 0) return TSR_OK;
     const bool full = mb->CH == 4 * mb->KBF;
     const void *kern = nullptr;
-    switch (mb->KBF * 2 + (full ? 1 : 0)) {
+    switch (mb->n_phase > 1 ? 0 : mb->KBF * 2 + (full ? 1 : 0)) {
+    case 0: kern = reinterpret_cast<const void *>(mx_bank_kernel<3, true, true>); break;
     case 2: kern = reinterpret_cast<const void *>(mx_bank_kernel<1, false>); break;
     case 3: kern = reinterpret_cast<const void *>(mx_bank_kernel<1, true>); break;
     case 4: kern = reinterpret_cast<const void *>(mx_bank_kernel<2, false>); break;
@@ -803,7 +853,8 @@ int tsr_launch_mx_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, float
     // (per launch: the attribute belongs to the function on the CURRENT device, and a process may hold several contexts)
     TSR_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS));
     MxArgs a;
-    a.bits = mc->d_bits; a.B = mb->d_B; a.groups = mc->d_groups; a.wg = mc->d_wg; a.cols = mb->d_cols;
+    a.bits = mc->ext_bits ? mc->ext_bits : mc->d_bits; a.B = mb->d_B;
+    a.n_phase = mb->n_phase; a.DWr = mc->DWr; a.bits_phase = mc->bits_phase; a.B_phase = (long long)mb->NKB * 3 * 1536; a.groups = mc->d_groups; a.wg = mc->d_wg; a.cols = mb->d_cols;
     {   // (development override: TSR_MX_SLOWCAP)
         const char *e = getenv("TSR_MX_SLOWCAP");
         a.slow_cap = e ? atoi(e) : (mb->NKB * 13 + 63) / 64 / 2 + 1;

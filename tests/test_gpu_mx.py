@@ -212,3 +212,67 @@ def test_mx_all_scores_pass(tsr_hip, oracle, shape):
     assert rel_err(allm, alle) <= TOL
     dc.close()
     bank.close()
+
+
+@pytest.mark.parametrize("case", [
+    dict(K=50, F=25, Ts=[60] * 30 + [34, 200, 32, 46], thr=12, spread=(2, 2), L=[20, 24, 28, 32, 32, 30, 26, 22]),   # D = 1050: three phases of 11 dwords
+    dict(K=50, F=45, Ts=[200] * 12, thr=12, spread=(2, 2), L=[32] * 8),                                              # config 3's rows: D = 2050, six phases
+    dict(K=30, F=28, Ts=[64, 40, 90, 38], thr=10, spread=(1, 1), L=[32, 36, 33]),                                    # D = 720: two phases of 12 dwords
+], ids=["D1050", "D2050", "D720"])
+def test_mx_wide_rows_in_feature_phases(tsr_hip, oracle, case):
+    """Part corpora (rows wider than 512 features, resident as bit rows): the MX kernel goes through the features in the
+    phases of the corpus' own bit form with one accumulator set.  Against the integer emulation, TSR_FAST and the oracle;
+    the all-scores pass too (its maximum equal to the fused pass bit for bit: sums beyond 2^24 round in f32, and the kernel
+    adds the K-blocks of wide rows in a fixed order so that every launch rounds alike).  A corpus with an odd utterance is served by TSR_FAST's kernels (same results as TSR_FAST)."""
+    from tsr_hip import synth
+    ctx = tsr_hip.default_ctx()
+    rng = np.random.default_rng(case["K"] + case["F"])
+    K, F, Ts = case["K"], case["F"], case["Ts"]
+    edges = [synth.features(rng, T, rng.uniform(0.05, 0.45, size=(F, 8))) for T in Ts]
+    offs = np.concatenate(([0], np.cumsum(Ts))).astype(np.int64)
+    lp, lip = synth.parts(rng, K)
+    corpus = tsr_hip.Corpus(np.concatenate(edges).reshape(int(offs[-1]), -1), offs)
+    parts = tsr_hip.Parts(lp, lip)
+    pc = corpus.part_features(parts, case["thr"], spread=case["spread"])
+    assert pc.layout()["bits"] and pc.D > 512
+    bank_cs = synth.bank(rng, synth.background(rng, (pc.D // K, K)), case["L"])
+    bank = tsr_hip.Bank(bank_cs)
+    pc.score(bank, tsr_hip.TSR_FAST | tsr_hip.TSR_MX)
+    assert ctx.get_option(tsr_hip.TSR_INFO_LAST_BANK_KERNEL) == tsr_hip.TSR_KERNEL_MX
+    s, a = pc.download()
+    allm = pc.score_all(bank, tsr_hip.TSR_FAST | tsr_hip.TSR_MX)
+    assert ctx.get_option(tsr_hip.TSR_INFO_LAST_BANK_KERNEL) == tsr_hip.TSR_KERNEL_MX
+    for _ in range(3):
+        pc.score(bank, tsr_hip.TSR_FAST | tsr_hip.TSR_MX)
+        s_again, a_again = pc.download()
+        assert np.array_equal(s, s_again) and np.array_equal(a, a_again)
+    pc.score(bank, tsr_hip.TSR_FAST)
+    sf, af = pc.download()
+    feats = pc.download_feats()
+    po = pc.offsets
+    es, ea, vals, slack = _emulate(feats, po, bank_cs)
+    assert np.all(np.abs(s - es) <= slack + 1e-30), float(np.max(np.abs(s - es) - slack))
+    assert np.all(np.abs(allm - vals) <= slack[None, :] + 1e-30)
+    assert np.array_equal(allm.max(0), s)
+    top2 = np.sort(vals, axis=0)[-2:]
+    clear = (top2[1] - top2[0]) > 4 * slack
+    assert np.array_equal(a[clear], ea[clear])
+    so, ao = oracle.score_corpus(feats, po, bank_cs)
+    assert rel_err(s, so) <= TOL and rel_err(sf, so) <= TOL
+    pc.close()
+    corpus.close()
+    # one odd utterance: the pair tiles need every utterance to start at an even row of the corpus' bit form
+    Ts2 = [Ts[0] + 1] + list(Ts[1:3])
+    offs2 = np.concatenate(([0], np.cumsum(Ts2))).astype(np.int64)
+    e2 = [synth.features(rng, T, rng.uniform(0.05, 0.45, size=(F, 8))) for T in Ts2]
+    corpus2 = tsr_hip.Corpus(np.concatenate(e2).reshape(int(offs2[-1]), -1), offs2)
+    pc2 = corpus2.part_features(parts, case["thr"], spread=case["spread"])
+    pc2.score(bank, tsr_hip.TSR_FAST | tsr_hip.TSR_MX)
+    assert ctx.get_option(tsr_hip.TSR_INFO_LAST_BANK_KERNEL) != tsr_hip.TSR_KERNEL_MX
+    s2, a2 = pc2.download()
+    pc2.score(bank, tsr_hip.TSR_FAST)
+    s3, a3 = pc2.download()
+    assert np.array_equal(s2, s3) and np.array_equal(a2, a3)
+    pc2.close()
+    corpus2.close()
+    bank.close()

@@ -1,6 +1,6 @@
 """Time BASELINE config 3 on the device: edge corpus -> code_parts / argmax / spread -> D = 2050 bank, with the part
 corpus resident as bit rows (default) and as byte rows (round 2's layout), hipEvent times per stage.
-    python tools/time_config3.py [N=1000] [bits,bytes] [reps=5]"""
+    python tools/time_config3.py [N=1000] [bits,bytes] [reps=5] [fast|mx]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "template-speech-recognition_amd"))
 import numpy as np
@@ -9,6 +9,7 @@ from tsr_hip import synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 LAYOUTS = (sys.argv[2] if len(sys.argv) > 2 else "bits,bytes").split(",")
 REPS = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+FLAGS = tsr_hip.TSR_FAST | (tsr_hip.TSR_MX if len(sys.argv) > 4 and sys.argv[4] == "mx" else 0)
 OPT = {"bits": tsr_hip.TSR_PART_LAYOUT_BITS, "bytes": tsr_hip.TSR_PART_LAYOUT_BYTES, "auto": tsr_hip.TSR_OPT_AUTO}
 rng = np.random.default_rng(3)
 q = synth.background(rng, (45, 8))
@@ -27,10 +28,10 @@ for layout in LAYOUTS:
         ctx.sync(); t0 = time.perf_counter(); ctx.timer_start()
         pc = corpus.part_features(parts, 12, spread=(2, 2))
         g = ctx.timer_stop(); w = (time.perf_counter() - t0) * 1e3
-        pc.score(bank, tsr_hip.TSR_FAST); ctx.sync()
+        pc.score(bank, FLAGS); ctx.sync()
         ctx.timer_start()
         for _ in range(4):
-            pc.score(bank, tsr_hip.TSR_FAST)
+            pc.score(bank, FLAGS)
         b = ctx.timer_stop() / 4
         if rep:
             fe_wall.append(w); fe_gpu.append(g); bank_gpu.append(b)
@@ -46,4 +47,4 @@ for layout in LAYOUTS:
           "part corpus %.1f MB resident (%s); scores identical to the first layout: %s"
           % (N, layout, min(fe_gpu), min(fe_wall), min(bank_gpu), tot, frames / tot / 1e3, lay["feature_bytes"] / 1e6,
              "+".join(k for k in ("bits", "bytes") if lay[k]), same))
-print("coder:", parts.info())
+print("coder:", parts.info(), "bank kernel:", ctx.get_option(tsr_hip.TSR_INFO_LAST_BANK_KERNEL))
