@@ -279,11 +279,14 @@ def config3(ctx, corpus, flags, layout=None):
     edges.close()
     fe, bk = min(fe_ms[1:]), min(bank_ms[1:])
     traffic = None
-    tp = os.path.join(ROOT, "profiles", "r03_config3_traffic.json")
+    bank_kernel = KERNEL_NAMES.get(ctx.get_option(tsr_hip.TSR_INFO_LAST_BANK_KERNEL), "?")
+    # the stored traffic of the chain as this run's bank pass ran it (round 4: the mx kernel in feature phases; round 3: int8 K-phases)
+    tn = "r04_config3_traffic.json" if bank_kernel == KERNEL_NAMES.get(tsr_hip.TSR_KERNEL_MX) else "r03_config3_traffic.json"
+    tp = os.path.join(ROOT, "profiles", tn)
     if layout is None and os.path.exists(tp):
         tj = json.load(open(tp))
         traffic = {"hbm_bytes_per_chain": tj["hbm_bytes_per_chain"], "ratio_to_algorithmic": tj["ratio_to_algorithmic"],
-                   "source": "profiles/r03_config3_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
+                   "source": "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % tn,
                    "measured_in_this_run": False}
     return {"front_end_stream_ms": fe, "front_end_wall_ms": min(fe_wall[1:]), "bank_D2050_kernel_ms": bk,
             "frames_per_s": frames / ((fe + bk) * 1e-3), "frames": frames,
@@ -291,7 +294,8 @@ def config3(ctx, corpus, flags, layout=None):
             "patch_locations": info["locations"], "f64_rechecked": info["rechecked"], "traffic": traffic,
             "what": "code_parts(K=50,thr=12) -> argmax -> spread(2,2) -> 8x32-tap bank on D=2050, one GPU; front_end_stream_ms = "
                     "hipEvents around tsr_corpus_part_features (coder, f64 re-evaluation, dilation and the allocation of the "
-                    "output corpus), bank = one TSR_FAST pass over the resident part corpus"}
+                    "output corpus), bank = one pass with the headline's flags over the resident part corpus (bank_kernel says which kernel served it)",
+            "bank_kernel": bank_kernel}
 
 
 def long_corpus(ctx, corpus, bank, flags, times=10):

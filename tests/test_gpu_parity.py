@@ -748,11 +748,18 @@ def test_config3_fullsize_coders_agree(mods, oracle):
     pc_mfma.score(bank, tsr_hip.TSR_FAST)
     sf, af = pc_mfma.download()
     assert rel_err(sf, se) <= TOL
+    pc_mfma.score(bank, tsr_hip.TSR_FAST | tsr_hip.TSR_MX)   # round 4: wide rows on the block-scaled kernel, in feature phases
+    assert tsr_hip.default_ctx().get_option(tsr_hip.TSR_INFO_LAST_BANK_KERNEL) == tsr_hip.TSR_KERNEL_MX
+    sm, am = pc_mfma.download()
+    assert rel_err(sm, se) <= TOL
+    top2 = np.sort(pc_mfma.score_all(bank, tsr_hip.TSR_EXACT), axis=0)[-2:]
+    clear = (top2[1] - top2[0]) > 2 * TOL * np.maximum(np.abs(top2[1]), 1.0)
+    assert clear.mean() > 0.9 and np.array_equal(am[clear], ae[clear]) and np.array_equal(af[clear], ae[clear])
     for n0 in sample[:8]:                                 # the D = 2050 bank on the part corpus, against the oracle
         so, ao = oracle.score_bank(got[n0], bank_cs)
         sl = slice(pc_mfma.offsets[n0], pc_mfma.offsets[n0 + 1])
         assert np.array_equal(se[sl], so) and np.array_equal(ae[sl], ao)
-        assert rel_err(sf[sl], so) <= TOL
+        assert rel_err(sf[sl], so) <= TOL and rel_err(sm[sl], so) <= TOL
 
 
 # ---- phone-window classification ------------------------------------------------

@@ -1,4 +1,4 @@
-# Round-4 evidence (GPU box, repo root):  bash tools/profile_r04.sh [part ...]   parts: bench traffic sq stamps abl rate
+# Round-4 evidence (GPU box, repo root):  bash tools/profile_r04.sh [part ...]   parts: bench traffic sq stamps abl rate config3
 # Kernel stats and counters always come from separate rocprofv3 runs (--pmc with --kernel-trace only).
 cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out && export TMPDIR=/tmp
 PARTS=${@:-bench traffic sq stamps}
@@ -35,6 +35,10 @@ stamps)  # phase times of the mx kernel from the -DTSR_STAMP build (tools/build_
   python3 tools/mx_stamp_report.py gpurun_out/mx_stamps.txt > gpurun_out/r04_mx_stamps.txt && cat gpurun_out/r04_mx_stamps.txt || exit 1 ;;
 abl)     # development ablations (tools/abl_mx.sh build "1 4 5" first, here or locally)
   { bash tools/abl_mx.sh run "1 4 5"; python3 tools/time_fast.py 8 9 | tail -1; python3 tools/time_fast.py 8 1 | tail -1; } > gpurun_out/r04_mx_ablations.txt 2>&1; cat gpurun_out/r04_mx_ablations.txt ;;
+config3) # BASELINE config 3 with the bank pass on the mx kernel (feature phases): stage times, kernel stats, HBM traffic of the chain
+  { timeout -k 10 300 python3 tools/time_config3.py 1000 bits 5 fast | grep layout; timeout -k 10 300 python3 tools/time_config3.py 1000 bits 5 mx; } > gpurun_out/r04_config3_timing.txt 2>&1 && cat gpurun_out/r04_config3_timing.txt && \
+  bash tools/kstat3.sh 1000 bits 5 mx > gpurun_out/r04_config3.log 2>&1 && cp gpurun_out/ks3/ks3_kernel_stats.csv gpurun_out/r04_config3_kernel_stats.csv && \
+  bash tools/traffic3.sh bits mx > gpurun_out/r04_config3_traffic.txt 2>&1 && python3 tools/traffic3_json.py gpurun_out/r04_config3_traffic.txt gpurun_out/r04_config3_traffic.json mx || exit 1 ;;
 rate)    # issue rate of the block-scaled matrix instruction
   timeout -k 10 120 ./tools/ubench/mx_rate.bin > gpurun_out/r04_mx_rate_ubench.txt 2>&1; cat gpurun_out/r04_mx_rate_ubench.txt ;;
 esac

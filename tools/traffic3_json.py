@@ -17,7 +17,8 @@ for line in open(txt):
     if m and name and sec == m.group(1):
         data.setdefault(name, {})[sec] = {"calls": int(m.group(2)), "mean_KiB": float(m.group(3)), "sum_KiB": float(m.group(4))}
 # the kernels of the chain, by the stem of their names (the dilation kernel of the bit form changed during round 3)
-stems = ["part_chain_setup_kernel", "code_parts_mfma_kernel", "code_parts_recheck_kernel", "spread_", "fast_bank_kernel", "frag_epilogue_kernel", "out_geometry_kernel"]
+stems = ["part_chain_setup_kernel", "code_parts_mfma_kernel", "code_parts_recheck_kernel", "spread_", "fast_bank_kernel", "frag_epilogue_kernel", "mx_bank_kernel",
+         "out_geometry_kernel"]
 chain = [k for st in stems for k in data if st in k]
 front = next(v for k, v in data.items() if "code_parts_mfma_kernel" in k)["FETCH_SIZE"]["calls"]   # front-end calls in the run
 per = {}
@@ -26,7 +27,10 @@ for k in chain:
     if k not in data:
         continue
     f, w = data[k].get("FETCH_SIZE", {"sum_KiB": 0, "calls": 0}), data[k].get("WRITE_SIZE", {"sum_KiB": 0, "calls": 0})
-    if "fast_bank" in k or "frag_epilogue" in k:      # bank passes (several per front-end call): one epilogue each; the phases share a launch since the middle of round 3
+    if "mx_bank" in k:                                # round 4, TSR_FAST | TSR_MX: one launch per bank pass (feature phases inside the workgroup)
+        passes = float(f["calls"])
+        rd, wr = 2 * f["sum_KiB"] * 1024 / passes, w["sum_KiB"] * 1024 / passes
+    elif "fast_bank" in k or "frag_epilogue" in k:    # bank passes (several per front-end call): one epilogue each; the phases share a launch since the middle of round 3
         passes = float(next(v for kk, v in data.items() if "frag_epilogue" in kk)["FETCH_SIZE"]["calls"])
         rd, wr = 2 * f["sum_KiB"] * 1024 / passes, w["sum_KiB"] * 1024 / passes
     else:
@@ -37,6 +41,7 @@ alg = 366 * 200000
 j = {"workload": "BASELINE config 3: 1000 x 200 frames x 45 x 8 edges -> code_parts(K=50) -> argmax -> spread(2,2) -> D=2050 bank, bit form",
      "per_kernel_per_chain": per, "hbm_bytes_per_chain": total, "algorithmic_bytes": alg, "ratio_to_algorithmic": total / alg,
      "correction": "FETCH_SIZE x2 (gfx950, MI355X_MICROARCH.md HBM section); both counters in KiB",
-     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 tools/time_config3.py 1000 bits 3 (two passes; tools/traffic3.sh)"}
+     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 tools/time_config3.py 1000 bits 3 %s (two passes; tools/traffic3.sh)"
+                % (sys.argv[3] if len(sys.argv) > 3 else "fast")}
 json.dump(j, open(out, "w"), indent=1)
 print(json.dumps(j)[:600])
