@@ -110,6 +110,31 @@ struct MxCorpus {   // derived forms of a corpus: bit rows (once), the tile plan
     bool plan_unsupported = false;
 };
 
+// 32 resident bytes (0 / 1) -> one dword of bits: eight bytes become eight bits by one multiply (byte i lands on bit 56 + i,
+// no two partial products share a bit)
+__device__ inline uint32_t mx_pack32(const uint8_t *row, int nb /* bytes inside the row: a multiple of 16 */)
+{
+    if (nb <= 0) return 0;
+    const uint4 x0 = *reinterpret_cast<const uint4 *>(row);
+    uint4 x1 = make_uint4(0, 0, 0, 0);
+    if (nb > 16) x1 = *reinterpret_cast<const uint4 *>(row + 16);
+    auto pack8 = [](unsigned lo32, unsigned hi32) {
+        const unsigned long long x = ((unsigned long long)hi32 << 32) | lo32;
+        return (uint32_t)((x * 0x0102040810204080ull) >> 56);
+    };
+    return pack8(x0.x, x0.y) | (pack8(x0.z, x0.w) << 8) | (pack8(x1.x, x1.y) << 16) | (pack8(x1.z, x1.w) << 24);
+}
+
+__device__ inline int64_t mx_utt_of(const int64_t *voff, int64_t N, int64_t v)   // last u with voff[u] <= v
+{
+    int64_t lo = 0, hi = N;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (voff[mid] <= v) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 // bit rows at virtual positions from the resident byte rows (one-off per corpus)
 __global__ void mx_pack_bits_kernel(const uint8_t *feats, int Dp, const int64_t *off, const int64_t *voff, int64_t N, int DW,
                                     int64_t Pv, uint32_t *bits)
@@ -118,30 +143,32 @@ __global__ void mx_pack_bits_kernel(const uint8_t *feats, int Dp, const int64_t 
     if (idx >= Pv * DW) return;
     const int64_t v = idx / DW;
     const int w = (int)(idx - v * DW);
-    int64_t lo = 0, hi = N;   // last u with voff[u] <= v
-    while (hi - lo > 1) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (voff[mid] <= v) lo = mid; else hi = mid;
-    }
-    const int64_t t = v - voff[lo], T = off[lo + 1] - off[lo];
+    const int64_t u = mx_utt_of(voff, N, v);
+    const int64_t t = v - voff[u], T = off[u + 1] - off[u];
+    bits[idx] = t < T ? mx_pack32(feats + (off[u] + t) * (int64_t)Dp + 32 * w, Dp - 32 * w) : 0u;
+}
+
+// Wide rows, corpora with an utterance of odd length: this file's own copy of the bit form, phase-major like the corpus'
+// ([phase][row][pw dwords]) with every utterance on an even row -- from the corpus' bit form (same geometry) or its byte rows.
+__global__ void mx_pack_phase_kernel(const uint8_t *feats, int Dp, const uint32_t *src_bits, int64_t src_rows, const int64_t *off,
+                                     const int64_t *voff, int64_t N, int pw, int n_phase, int64_t Pv, int64_t rows_alloc, uint32_t *bits)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t plane = Pv * pw;
+    if (idx >= plane * n_phase) return;
+    const int ph = (int)(idx / plane);
+    const int64_t r = idx - (int64_t)ph * plane;
+    const int64_t v = r / pw;
+    const int w = (int)(r - v * pw);
+    const int64_t u = mx_utt_of(voff, N, v);
+    const int64_t t = v - voff[u], T = off[u + 1] - off[u];
     uint32_t word = 0;
     if (t < T) {
-        // resident bytes are 0 / 1: eight of them become eight bits by one multiply (byte i lands on bit 56 + i, no two
-        // partial products share a bit)
-        const uint8_t *row = feats + (off[lo] + t) * (int64_t)Dp + 32 * w;
-        const int nb = Dp - 32 * w;   // bytes this dword covers inside the row (a multiple of 16, at most 32)
-        if (nb > 0) {
-            const uint4 x0 = *reinterpret_cast<const uint4 *>(row);
-            uint4 x1 = make_uint4(0, 0, 0, 0);
-            if (nb > 16) x1 = *reinterpret_cast<const uint4 *>(row + 16);
-            auto pack8 = [](unsigned lo32, unsigned hi32) {
-                const unsigned long long x = ((unsigned long long)hi32 << 32) | lo32;
-                return (uint32_t)((x * 0x0102040810204080ull) >> 56);
-            };
-            word = pack8(x0.x, x0.y) | (pack8(x0.z, x0.w) << 8) | (pack8(x1.x, x1.y) << 16) | (pack8(x1.z, x1.w) << 24);
-        }
+        const int64_t p = off[u] + t;
+        const int gw = ph * pw + w;   // dword of the whole row
+        word = src_bits ? src_bits[((int64_t)ph * src_rows + p) * pw + w] : mx_pack32(feats + p * (int64_t)Dp + 32 * gw, Dp - 32 * gw);
     }
-    bits[idx] = word;
+    bits[((int64_t)ph * rows_alloc + v) * pw + w] = word;
 }
 
 constexpr int MX_STASH = 4096;                    // behind the LDS image: the workgroup's group records
@@ -700,19 +727,55 @@ static int mx_corpus_bits(tsr_ctx *ctx, tsr_corpus *cp, const MxBank *mb)
         mc = new MxCorpus;
         cp->mx = mc;
     }
+    const int64_t N = cp->N;
     if (mb->n_phase > 1) {
         // wide rows: the corpus' own resident bit form, read as it lies -- phase-major [phase][frame][pw dwords] -- when its
         // geometry is the bank's and every utterance has an even number of frames (a pair of starts must begin in the same
-        // frame parity of the LDS image; this file's own bit rows pad odd utterances, the corpus' form cannot)
+        // frame parity of the LDS image).  Otherwise a copy of that form with every utterance moved to an even row, built once.
         bool even = true;
-        for (int64_t u = 0; u < cp->N; ++u) even = even && ((cp->offsets[(size_t)u + 1] - cp->offsets[(size_t)u]) & 1) == 0;
-        if (!cp->d_bits || cp->bit_pw != mb->pw || cp->bit_nph != mb->n_phase || !even) return TSR_ERR_UNSUPPORTED;
-        mc->ext_bits = reinterpret_cast<const uint32_t *>(cp->d_bits);
-        mc->DWr = cp->bit_pw;
-        mc->bits_phase = (long long)cp->bit_rows * cp->bit_pw;
-        mc->voff.assign(cp->offsets.begin(), cp->offsets.end());
-        mc->Pv = cp->P;
-        mc->rows_alloc = cp->bit_rows;
+        for (int64_t u = 0; u < N; ++u) even = even && ((cp->offsets[(size_t)u + 1] - cp->offsets[(size_t)u]) & 1) == 0;
+        const bool same_geometry = cp->d_bits && cp->bit_pw == mb->pw && cp->bit_nph == mb->n_phase;
+        mc->DWr = mb->pw;
+        if (same_geometry && even) {
+            mc->ext_bits = reinterpret_cast<const uint32_t *>(cp->d_bits);
+            mc->bits_phase = (long long)cp->bit_rows * cp->bit_pw;
+            mc->voff.assign(cp->offsets.begin(), cp->offsets.end());
+            mc->Pv = cp->P;
+            mc->rows_alloc = cp->bit_rows;
+            return TSR_OK;
+        }
+        mc->ext_bits = nullptr;
+        if (mc->d_bits && mc->DW == -mb->pw) return TSR_OK;   // (DW < 0: the phase-major copy)
+        if (!same_geometry) TSR_TRY(tsr_corpus_need_bytes(ctx, cp));
+        mc->voff.assign((size_t)N + 1, 0);
+        for (int64_t u = 0; u < N; ++u) mc->voff[(size_t)u + 1] = mc->voff[(size_t)u] + ((cp->offsets[(size_t)u + 1] - cp->offsets[(size_t)u] + 1) & ~(int64_t)1);
+        mc->Pv = mc->voff[(size_t)N];
+        mc->DW = -mb->pw;
+        mc->rows_alloc = mc->Pv + 2 * (MX_LDS / 128 / 16 * 16) + 2;
+        mc->bits_phase = (long long)mc->rows_alloc * mb->pw;
+        const size_t bytes = (size_t)mb->n_phase * mc->rows_alloc * mb->pw * 4 + 256;   // (+ 256: the last piece of a row reads up to 12 dwords)
+        TSR_HIP(hipMalloc(reinterpret_cast<void **>(&mc->d_bits), bytes));
+        TSR_HIP(hipMemsetAsync(mc->d_bits, 0, bytes, ctx->stream));
+        int64_t *d_tab = nullptr;
+        TSR_HIP(hipMalloc(reinterpret_cast<void **>(&d_tab), (size_t)(N + 1) * 16));
+        hipError_t e = hipMemcpyAsync(d_tab, cp->offsets.data(), (size_t)(N + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_tab + (N + 1), mc->voff.data(), (size_t)(N + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && mc->Pv > 0) {
+            const int64_t total = mc->Pv * mb->pw * mb->n_phase;
+            hipLaunchKernelGGL(mx_pack_phase_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, cp->d_feats, cp->Dp,
+                               same_geometry ? reinterpret_cast<const uint32_t *>(cp->d_bits) : nullptr, cp->bit_rows, d_tab, d_tab + (N + 1), N,
+                               mb->pw, mb->n_phase, mc->Pv, mc->rows_alloc, mc->d_bits);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_tab);
+        if (e != hipSuccess) {
+            (void)hipFree(mc->d_bits);
+            mc->d_bits = nullptr;
+            mc->DW = 0;
+            tsr_set_error("TSR_MX: building the phase-major bit rows failed: %s", hipGetErrorString(e));
+            return TSR_ERR_HIP;
+        }
         return TSR_OK;
     }
     const int DW = 4 * KBF;
@@ -726,7 +789,6 @@ static int mx_corpus_bits(tsr_ctx *ctx, tsr_corpus *cp, const MxBank *mb)
         TSR_HIP(hipFree(mc->d_bits));
         mc->d_bits = nullptr;
     }
-    const int64_t N = cp->N;
     mc->voff.assign((size_t)N + 1, 0);
     for (int64_t u = 0; u < N; ++u) mc->voff[(size_t)u + 1] = mc->voff[(size_t)u] + ((cp->offsets[(size_t)u + 1] - cp->offsets[(size_t)u] + 1) & ~(int64_t)1);
     mc->Pv = mc->voff[(size_t)N];

@@ -163,11 +163,10 @@ def test_mx_long_utterance(tsr_hip, oracle):
 
 
 def test_mx_requests_outside_its_envelope_are_served_as_fast(tsr_hip, oracle):
-    """More than eight templates, rows wider than 512 features and short filters fall to TSR_FAST's int8 kernels: same
-    results as plain TSR_FAST, bit for bit."""
+    """More than eight templates and short filters fall to TSR_FAST's int8 kernels: same results as plain TSR_FAST, bit
+    for bit."""
     from tsr_hip import synth
-    for shape in (dict(N=3, T=[90, 140, 60], F=45, E=8, M=9, L=32), dict(N=2, T=[70, 90], F=80, E=8, M=4, L=32),
-                  dict(N=3, T=[40, 50, 30], F=6, E=5, M=3, L=9)):
+    for shape in (dict(N=3, T=[90, 140, 60], F=45, E=8, M=9, L=32), dict(N=3, T=[40, 50, 30], F=6, E=5, M=3, L=9)):
         c = synth.corpus(31, **shape)
         P = int(c["offsets"][-1])
         f2 = c["feats"].reshape(P, -1)
@@ -223,7 +222,8 @@ def test_mx_wide_rows_in_feature_phases(tsr_hip, oracle, case):
     """Part corpora (rows wider than 512 features, resident as bit rows): the MX kernel goes through the features in the
     phases of the corpus' own bit form with one accumulator set.  Against the integer emulation, TSR_FAST and the oracle;
     the all-scores pass too (its maximum equal to the fused pass bit for bit: sums beyond 2^24 round in f32, and the kernel
-    adds the K-blocks of wide rows in a fixed order so that every launch rounds alike).  A corpus with an odd utterance is served by TSR_FAST's kernels (same results as TSR_FAST)."""
+    adds the K-blocks of wide rows in a fixed order so that every launch rounds alike).  A corpus with an utterance of odd
+    length, and the same frames as byte rows, go through the kernel's own phase-major copy."""
     from tsr_hip import synth
     ctx = tsr_hip.default_ctx()
     rng = np.random.default_rng(case["K"] + case["F"])
@@ -261,18 +261,28 @@ def test_mx_wide_rows_in_feature_phases(tsr_hip, oracle, case):
     assert rel_err(s, so) <= TOL and rel_err(sf, so) <= TOL
     pc.close()
     corpus.close()
-    # one odd utterance: the pair tiles need every utterance to start at an even row of the corpus' bit form
-    Ts2 = [Ts[0] + 1] + list(Ts[1:3])
+    # an utterance of odd length: the kernel reads its own phase-major copy of the bit form, every utterance on an even row
+    Ts2 = [Ts[0] + 1] + list(Ts[1:3]) + [Ts[0] - 1]
     offs2 = np.concatenate(([0], np.cumsum(Ts2))).astype(np.int64)
     e2 = [synth.features(rng, T, rng.uniform(0.05, 0.45, size=(F, 8))) for T in Ts2]
     corpus2 = tsr_hip.Corpus(np.concatenate(e2).reshape(int(offs2[-1]), -1), offs2)
     pc2 = corpus2.part_features(parts, case["thr"], spread=case["spread"])
+    assert any(int(t) & 1 for t in np.diff(pc2.offsets))
     pc2.score(bank, tsr_hip.TSR_FAST | tsr_hip.TSR_MX)
-    assert ctx.get_option(tsr_hip.TSR_INFO_LAST_BANK_KERNEL) != tsr_hip.TSR_KERNEL_MX
+    assert ctx.get_option(tsr_hip.TSR_INFO_LAST_BANK_KERNEL) == tsr_hip.TSR_KERNEL_MX
     s2, a2 = pc2.download()
-    pc2.score(bank, tsr_hip.TSR_FAST)
-    s3, a3 = pc2.download()
-    assert np.array_equal(s2, s3) and np.array_equal(a2, a3)
+    feats2 = pc2.download_feats()
+    es2, ea2, vals2, slack2 = _emulate(feats2, pc2.offsets, bank_cs)
+    assert np.all(np.abs(s2 - es2) <= slack2 + 1e-30)
+    so2, ao2 = oracle.score_corpus(feats2, pc2.offsets, bank_cs)
+    assert rel_err(s2, so2) <= TOL
+    # the same frames handed over as byte rows (a host corpus): packed into the phase-major form from the bytes
+    dc = tsr_hip.Corpus(feats2, pc2.offsets)
+    dc.score(bank, tsr_hip.TSR_FAST | tsr_hip.TSR_MX)
+    assert ctx.get_option(tsr_hip.TSR_INFO_LAST_BANK_KERNEL) == tsr_hip.TSR_KERNEL_MX
+    s3, a3 = dc.download()
+    assert np.array_equal(s3, s2) and np.array_equal(a3, a2)
+    dc.close()
     pc2.close()
     corpus2.close()
     bank.close()

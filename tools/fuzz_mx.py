@@ -18,7 +18,7 @@ ctx = tsr_hip.default_ctx()
 bad = served = 0
 for case in range(n_cases):
     M = int(rng.choice([1, 2, 3, 5, 7, 8, 8, 8, 9, 12]))
-    F, E = [(45, 8), (16, 8), (64, 8), (26, 5), (33, 3), (9, 16), (80, 8), (6, 5)][int(rng.integers(8))]
+    F, E = [(45, 8), (16, 8), (64, 8), (26, 5), (33, 3), (9, 16), (80, 8), (6, 5), (131, 8), (41, 50)][int(rng.integers(10))]   # (D > 512: feature phases)
     D = F * E
     Lmin = max(2, 4096 // D + 1) if rng.random() < 0.9 else 2
     Ls = [int(x) for x in rng.integers(Lmin, Lmin + 30, size=M)]
@@ -43,7 +43,7 @@ for case in range(n_cases):
         sf, af = bank.score(f2, c["offsets"], flags=tsr_hip.TSR_FAST)
         if not (np.array_equal(s, sf) and np.array_equal(a, af)):
             msg += " fallback != TSR_FAST"
-        if P and M <= 8 and D <= 512 and min(Ls) * D > 4096:
+        if P and M <= 8 and min(Ls) * D > 4096 and (D <= 512 or max(Ls) >= 12):   # (wide rows: at least 24 K-blocks per phase)
             msg += " inside the envelope but not served by the MX kernel"
     else:
         served += 1
