@@ -211,8 +211,10 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
     // lie in registers and across ONE lane pair (lane ^ 16) and the maximum over them is three in-lane compares and one exchange
     const int s = lane >> 5, h = (lane >> 4) & 1;
     MxCol col[4];
+    if constexpr (!PHASES) {   // (requested with everything else; the phase loop would only spill them: it loads them behind the loop)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) col[g] = a.cols[4 * (lane >> 4) + g];
+        for (int g = 0; g < 4; ++g) col[g] = a.cols[4 * (lane >> 4) + g];
+    }
     MxGroup G = {v_lo, 0, 0, 0};
     if (tid < MX_GROUPS) {
         const int gi = tile_beg * 16 + tid;
@@ -233,9 +235,11 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
     // slots; at most 2 * KBF * NR <= 2496 pieces = five per thread
     u32x4 piece[5];
     int dst[5], cpiece[5];
+    int tidp = tid;
+    if constexpr (PHASES) asm volatile("" : "+v"(tidp));   // (keeps the staging addresses from being hoisted out of the phase loop, where they would be spilled)
 #pragma unroll
     for (int it = 0; it < 5; ++it) {
-        const int idx = tid + it * (MX_WAVES * 64);
+        const int idx = tidp + it * (MX_WAVES * 64);
         const int pass = idx / nrows, r = idx - pass * nrows;
         const int plane = pass & 1, kbf = pass >> 1;
         const int fr = 2 * r + plane;
@@ -434,6 +438,10 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
     while (kblock(b4, b2, e4, e2) && kblock(d4, d2, b4, b2) && kblock(e4, e2, d4, d2)) {
     }
     }   // (feature phases)
+    if constexpr (PHASES) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) col[g] = a.cols[4 * (lane >> 4) + g];
+    }
 
     MX_STAMP(3)
     // ---- the eight partial sums of a tile meet in LDS (the frames are done with): tile j belongs to wave j & 7 ----

@@ -127,24 +127,30 @@ if bench and "modes" in bench:
                      "%s of the int8 peak; %s TB/s of algorithmic bytes" % (f(x10["frac_of_int8_peak"], "%.3f"), f(x10["hbm_gbs_alg"] / 1e3, "%.2f")),
                      "the steady-state loop (matrix pipe 81 % busy inside it)"))
 # ---- config 3 -----------------------------------------------------------------------------------------------------
-c3 = {k: kavg("config3_kernel_stats.csv", k) for k in ("code_parts_mfma_kernel", "code_parts_recheck_kernel", "spread_",
+c3 = {k: kavg("config3_kernel_stats.csv", k) for k in ("code_parts_mfma_kernel", "code_parts_recheck_kernel", "spread_", "mx_bank_kernel",
                                                         "fast_bank_kernel<11, 2, false, 2, 1, true>", "frag_epilogue_kernel", "part_chain_setup_kernel")}
 t3 = jload("config3_traffic.json")
 if c3["code_parts_mfma_kernel"][0]:
-    # bank launches per pass: one since the K-phases share a launch (one epilogue per pass either way)
-    nb, ne = c3["fast_bank_kernel<11, 2, false, 2, 1, true>"][1], c3["frag_epilogue_kernel"][1]
-    per_pass = (nb / ne) if ne else 1
-    bank = per_pass * c3["fast_bank_kernel<11, 2, false, 2, 1, true>"][0] + c3["frag_epilogue_kernel"][0]
+    if c3["mx_bank_kernel"][0]:   # round 4: the bank pass on the block-scaled kernel, feature phases inside the workgroup
+        bank = c3["mx_bank_kernel"][0]
+        bank_label = "`mx_bank_kernel<3,true,PHASES>` (`TSR_FAST|TSR_MX`: six feature phases over the corpus' bit form, one launch, no epilogue)"
+        bound = "instructions beside the matrix cores (coder: three per part-slot key); bank: as the config-2 kernel, per phase"
+    else:
+        # bank launches per pass: one since the K-phases share a launch (one epilogue per pass either way)
+        nb, ne = c3["fast_bank_kernel<11, 2, false, 2, 1, true>"][1], c3["frag_epilogue_kernel"][1]
+        per_pass = (nb / ne) if ne else 1
+        bank = per_pass * c3["fast_bank_kernel<11, 2, false, 2, 1, true>"][0] + c3["frag_epilogue_kernel"][0]
+        bank_label = "`fast_bank_kernel<11,2,bits>` (6 K-phases in %s launch%s) + epilogue" % ("one" if per_pass < 1.5 else "%d" % round(per_pass), "" if per_pass < 1.5 else "es")
+        bound = "instructions beside the matrix cores (coder: three per part-slot key; bank: 22 MFMAs per skew emission)"
     setup = c3["part_chain_setup_kernel"][0] or 0.0
     tot = c3["code_parts_mfma_kernel"][0] + c3["code_parts_recheck_kernel"][0] + c3["spread_"][0] + bank + setup
-    rows.append(("config-3 chain: setup + `code_parts_mfma_kernel<7>` + recheck + `spread_lane_bits_kernel` (dilation into the bit form) + `fast_bank_kernel<11,2,bits>` (6 K-phases in %s launch%s) + epilogue"
-                 % ("one" if per_pass < 1.5 else "%d" % round(per_pass), "" if per_pass < 1.5 else "es"),
+    rows.append(("config-3 chain: setup + `code_parts_mfma_kernel<7>` + recheck + `spread_lane_bits_kernel` (dilation into the bit form) + " + bank_label,
                  "config 3: 8.2 M locations x 50 parts; D = 2050 bank", "164 + 177 Gflop, 73.2 MB algorithmic",
                  "%s + %s + %s + %s + %s = %s us of kernels (`%s`)"
                  % (f(setup), f(c3["code_parts_mfma_kernel"][0]), f(c3["code_parts_recheck_kernel"][0]), f(c3["spread_"][0]), f(bank), f(tot), tag("config3_kernel_stats.csv")),
-                 "%s Tflop/s over the chain; PMC traffic %s MB = %sx algorithmic (`%s`; round 2: ~950 MB by its own sizes)"
+                 "%s Tflop/s over the chain; PMC traffic %s MB = %sx algorithmic (`%s`; round 3: 317 MB, round 2: ~950 MB by its own sizes)"
                  % (f(341e9 / tot / 1e6, "%.0f"), f(t3["hbm_bytes_per_chain"] / 1e6 if t3 else None, "%.0f"), f(t3["ratio_to_algorithmic"] if t3 else None, "%.1f"), tag("config3_traffic.json")),
-                 "instructions beside the matrix cores (coder: three per part-slot key; bank: 22 MFMAs per skew emission)"))
+                 bound))
 # ---- config 4 share -----------------------------------------------------------------------------------------------
 us4, c4 = kavg("c45_kernel_stats.csv", "tap2_bank_kernel")
 if us4:
