@@ -189,7 +189,16 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
     const int CH = a.CH, nfull = a.nfull;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if MX_ABL & 32   // development ablation: config 2's plan computed instead of loaded (what the dependent load of the plan costs)
+    int4 wg;
+    {
+        const int b = blockIdx.x, g0 = 336 * b, g1 = min(336 * b + 335, a.n_groups - 1);
+        const int v0 = 200 * (g0 / 85) + 2 * (g0 % 85), v1 = 200 * (g1 / 85) + 2 * (g1 % 85);
+        wg = make_int4(21 * b, min(21, (a.n_groups + 15) / 16 - 21 * b), v0, v1 + 33 - v0);
+    }
+#else
     const int4 wg = a.wg[blockIdx.x];
+#endif
     const int tile_beg = wg.x, nt = wg.y, v_lo = wg.z, nfr = wg.w;
     const int NR = a.NR;
     int *const g_row = reinterpret_cast<int *>(lds + MX_IMAGE);   // [336] LDS row of the group's first frame
