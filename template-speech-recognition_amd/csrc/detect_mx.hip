@@ -69,6 +69,7 @@ struct MxArgs {
     int n_groups, NKB, KBF, NR, Lmin, idmax;
     int CH, nfull, packed, M;
     int slow_cap;             // K-blocks a wave of the slower half (waves 4..7) takes at most
+    int fixed;                // K-blocks in fixed shares (wave w: w, w + 8, ...): banks whose sums may pass 2^24, where the order of the f32 additions shows
     int n_phase, DWr;         // feature phases (rows wider than 512 features: one staging + K loop per phase, one accumulator set); dwords per bit row
     long long bits_phase, B_phase;   // dwords / bytes from one phase's bit rows / fragments to the next    // chunk arrays per frame parity; full 32-feature chunks of a row; leftover features of four tap rows share a chunk
     float cmax;
@@ -90,6 +91,7 @@ struct MxArgs {
 
 struct MxBank {
     int KBF = 0, ROWS = 0, NKB = 0, NR = 0, Lmin = 0, Lmax = 0, idmax = 0, CH = 0, nfull = 0, packed = 0, n_phase = 1, pw = 0;
+    bool exact = true;        // no sum of the bank's weights over any set of taps reaches 2^24
     int32_t *d_kq = nullptr;
     float cmax = 0;
     unsigned char *d_B = nullptr;
@@ -370,9 +372,10 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
         // two ahead it would still hold two of them when the pool is empty.  It stops drawing after slow_cap K-blocks and
         // the older half finishes the pool.
         ++taken;
-        if (lane == 0 && (wave < 4 || taken + 2 < a.slow_cap))
+        // (a.fixed: a bank whose sums can pass 2^24 takes fixed shares here too -- same bits from launch to launch)
+        if (lane == 0 && !a.fixed && (wave < 4 || taken + 2 < a.slow_cap))
             kb_3 = (int)__hip_atomic_fetch_add(next_kb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        else if (lane == 0) kb_3 = a.NKB;
+        else if (lane == 0) kb_3 = a.fixed ? kb_2 + MX_WAVES : a.NKB;
         }
 #endif
         const bool more = kb_1 < a.NKB;
@@ -594,7 +597,7 @@ void tsr_mx_corpus_free(tsr_corpus *cp)
     cp->mx = nullptr;
 }
 
-// The bank's fragments.  TSR_ERR_UNSUPPORTED: more than 8 templates, rows wider than 512 features, or filters so long
+// The bank's fragments.  TSR_ERR_UNSUPPORTED: more than 8 templates, fewer than 24 K-blocks (per phase), or filters so long
 // that not even one tile's frames fit the LDS image.
 static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
 {
@@ -628,7 +631,10 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
     const int CHw = nfull + (lo ? 1 : 0);                      // chunks of a row that carry weights
     const int CH = n_phase > 1 ? 4 * KBF : CHw;                // chunk arrays per frame parity in the LDS image (phases: four per
                                                                // staged piece, so that the staging needs no per-chunk checks)
-    const int NR = MX_IMAGE / (32 * CH) / 16 * 16;             // rows per array: a multiple of 16 (conflict-free fragment reads)
+    // rows per array: a multiple of 16 (conflict-free fragment reads), as many as the image holds -- and no more than the
+    // staging covers (five 16-byte pieces per thread: 2 KBF NR <= 2560; narrow rows would otherwise get arrays longer than
+    // a workgroup of short utterances can fill in one staging pass)
+    const int NR = std::min(MX_IMAGE / (32 * CH), 5 * MX_WAVES * 64 / (2 * KBF)) / 16 * 16;
     struct ChunkRef { int plane, c, rho, k0; };                // c < nfull: features 32 c .. of tap row rho; c == nfull && packed: leftovers of
     std::vector<ChunkRef> refs;                                // the tap rows plane + 2 (k0 .. k0 + 3); c == nfull && !packed: the partly filled chunk
     for (int plane = 0; plane < 2; ++plane) {
@@ -661,6 +667,18 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
         if (m == 0 || cf > cmax) { cmax = cf; idmax = m; }
     }
     mb->cmax = cmax; mb->idmax = idmax;
+    // Can a sum of this bank's fixed-point weights over any set of taps reach 2^24?  Below that every partial sum is an
+    // exact integer in f32 and the order of the additions cannot show; from there on the kernel takes its K-blocks in fixed
+    // shares, so that every launch rounds alike.
+    mb->exact = true;
+    for (int m = 0; m < M; ++m) {
+        double pos = 0, neg = 0;
+        for (int64_t i = woff[m]; i < woff[m + 1]; ++i) {
+            const double q = nearbyint((double)bank->W_cat[(size_t)i] * scale[m]);
+            (q > 0 ? pos : neg) += fabs(q);
+        }
+        if (std::max(pos, neg) >= 16777216.0) mb->exact = false;
+    }
     for (int n = 0; n < 16; ++n) {
         const int m = n & 7;
         if (m < M) cols[n] = MxCol{(float)(1.0 / scale[m]), (float)bank->c[m], bank->L[m], m};
@@ -735,22 +753,66 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
     return TSR_OK;
 }
 
-// Bit rows of the corpus at virtual positions (every utterance starts on an even row), built once.
+// Bit rows of the corpus at virtual positions (every utterance starts on an even row), built once.  `pw` = 0: one phase,
+// rows of DW dwords from the resident byte rows; `pw` > 0: phase-major [phase][row][pw dwords] from the corpus' own bit form
+// (src_bits) or its byte rows.  On failure nothing stays behind that a later call could take for a finished form.
+static int mx_build_rows(tsr_ctx *ctx, tsr_corpus *cp, MxCorpus *mc, int DW, int pw, int n_phase, const uint32_t *src_bits)
+{
+    const int64_t N = cp->N;
+    if (mc->d_bits) {
+        TSR_HIP(hipStreamSynchronize(ctx->stream));
+        TSR_HIP(hipFree(mc->d_bits));
+        mc->d_bits = nullptr;
+    }
+    mc->DW = 0;
+    mc->voff.assign((size_t)N + 1, 0);
+    for (int64_t u = 0; u < N; ++u) mc->voff[(size_t)u + 1] = mc->voff[(size_t)u] + ((cp->offsets[(size_t)u + 1] - cp->offsets[(size_t)u] + 1) & ~(int64_t)1);
+    mc->Pv = mc->voff[(size_t)N];
+    mc->rows_alloc = mc->Pv + 2 * (MX_LDS / 128 / 16 * 16) + 2;   // read-ahead of the last workgroup: at most one LDS image of rows
+    const int row_dw = pw ? pw : DW, planes = pw ? n_phase : 1;
+    const size_t bytes = (size_t)planes * mc->rows_alloc * row_dw * 4 + 256;   // (+ 256: the last piece of a phase row reads up to 12 dwords)
+    uint32_t *d_rows = nullptr;
+    int64_t *d_tab = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_rows), bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(d_rows, 0, bytes, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_tab), (size_t)(N + 1) * 16);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_tab, cp->offsets.data(), (size_t)(N + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_tab + (N + 1), mc->voff.data(), (size_t)(N + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && mc->Pv > 0) {
+        const int64_t total = mc->Pv * row_dw * planes;
+        if (pw)
+            hipLaunchKernelGGL(mx_pack_phase_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, cp->d_feats, cp->Dp, src_bits,
+                               cp->bit_rows, d_tab, d_tab + (N + 1), N, pw, n_phase, mc->Pv, mc->rows_alloc, d_rows);
+        else
+            hipLaunchKernelGGL(mx_pack_bits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, cp->d_feats, cp->Dp, d_tab,
+                               d_tab + (N + 1), N, DW, mc->Pv, d_rows);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_tab);
+    if (e != hipSuccess) {
+        (void)hipFree(d_rows);
+        tsr_set_error("TSR_MX: building the bit rows failed: %s", hipGetErrorString(e));
+        return TSR_ERR_HIP;
+    }
+    mc->d_bits = d_rows;
+    mc->DW = pw ? -pw : DW;   // (DW < 0: the phase-major copy)
+    return TSR_OK;
+}
+
 static int mx_corpus_bits(tsr_ctx *ctx, tsr_corpus *cp, const MxBank *mb)
 {
-    const int KBF = mb->KBF;
     MxCorpus *mc = mxc(cp);
     if (!mc) {
         mc = new MxCorpus;
         cp->mx = mc;
     }
-    const int64_t N = cp->N;
     if (mb->n_phase > 1) {
         // wide rows: the corpus' own resident bit form, read as it lies -- phase-major [phase][frame][pw dwords] -- when its
         // geometry is the bank's and every utterance has an even number of frames (a pair of starts must begin in the same
         // frame parity of the LDS image).  Otherwise a copy of that form with every utterance moved to an even row, built once.
         bool even = true;
-        for (int64_t u = 0; u < N; ++u) even = even && ((cp->offsets[(size_t)u + 1] - cp->offsets[(size_t)u]) & 1) == 0;
+        for (int64_t u = 0; u < cp->N; ++u) even = even && ((cp->offsets[(size_t)u + 1] - cp->offsets[(size_t)u]) & 1) == 0;
         const bool same_geometry = cp->d_bits && cp->bit_pw == mb->pw && cp->bit_nph == mb->n_phase;
         mc->DWr = mb->pw;
         if (same_geometry && even) {
@@ -762,79 +824,20 @@ static int mx_corpus_bits(tsr_ctx *ctx, tsr_corpus *cp, const MxBank *mb)
             return TSR_OK;
         }
         mc->ext_bits = nullptr;
-        if (mc->d_bits && mc->DW == -mb->pw) return TSR_OK;   // (DW < 0: the phase-major copy)
-        if (!same_geometry) TSR_TRY(tsr_corpus_need_bytes(ctx, cp));
-        mc->voff.assign((size_t)N + 1, 0);
-        for (int64_t u = 0; u < N; ++u) mc->voff[(size_t)u + 1] = mc->voff[(size_t)u] + ((cp->offsets[(size_t)u + 1] - cp->offsets[(size_t)u] + 1) & ~(int64_t)1);
-        mc->Pv = mc->voff[(size_t)N];
-        mc->DW = -mb->pw;
-        mc->rows_alloc = mc->Pv + 2 * (MX_LDS / 128 / 16 * 16) + 2;
+        if (!(mc->d_bits && mc->DW == -mb->pw)) {
+            if (!same_geometry) TSR_TRY(tsr_corpus_need_bytes(ctx, cp));
+            TSR_TRY(mx_build_rows(ctx, cp, mc, 0, mb->pw, mb->n_phase, same_geometry ? reinterpret_cast<const uint32_t *>(cp->d_bits) : nullptr));
+        }
         mc->bits_phase = (long long)mc->rows_alloc * mb->pw;
-        const size_t bytes = (size_t)mb->n_phase * mc->rows_alloc * mb->pw * 4 + 256;   // (+ 256: the last piece of a row reads up to 12 dwords)
-        TSR_HIP(hipMalloc(reinterpret_cast<void **>(&mc->d_bits), bytes));
-        TSR_HIP(hipMemsetAsync(mc->d_bits, 0, bytes, ctx->stream));
-        int64_t *d_tab = nullptr;
-        TSR_HIP(hipMalloc(reinterpret_cast<void **>(&d_tab), (size_t)(N + 1) * 16));
-        hipError_t e = hipMemcpyAsync(d_tab, cp->offsets.data(), (size_t)(N + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_tab + (N + 1), mc->voff.data(), (size_t)(N + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess && mc->Pv > 0) {
-            const int64_t total = mc->Pv * mb->pw * mb->n_phase;
-            hipLaunchKernelGGL(mx_pack_phase_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, cp->d_feats, cp->Dp,
-                               same_geometry ? reinterpret_cast<const uint32_t *>(cp->d_bits) : nullptr, cp->bit_rows, d_tab, d_tab + (N + 1), N,
-                               mb->pw, mb->n_phase, mc->Pv, mc->rows_alloc, mc->d_bits);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        (void)hipFree(d_tab);
-        if (e != hipSuccess) {
-            (void)hipFree(mc->d_bits);
-            mc->d_bits = nullptr;
-            mc->DW = 0;
-            tsr_set_error("TSR_MX: building the phase-major bit rows failed: %s", hipGetErrorString(e));
-            return TSR_ERR_HIP;
-        }
         return TSR_OK;
     }
-    const int DW = 4 * KBF;
+    const int DW = 4 * mb->KBF;
     mc->ext_bits = nullptr;
     mc->DWr = DW;
     mc->bits_phase = 0;
     if (mc->d_bits && mc->DW == DW) return TSR_OK;
     TSR_TRY(tsr_corpus_need_bytes(ctx, cp));
-    if (mc->d_bits) {
-        TSR_HIP(hipStreamSynchronize(ctx->stream));
-        TSR_HIP(hipFree(mc->d_bits));
-        mc->d_bits = nullptr;
-    }
-    mc->voff.assign((size_t)N + 1, 0);
-    for (int64_t u = 0; u < N; ++u) mc->voff[(size_t)u + 1] = mc->voff[(size_t)u] + ((cp->offsets[(size_t)u + 1] - cp->offsets[(size_t)u] + 1) & ~(int64_t)1);
-    mc->Pv = mc->voff[(size_t)N];
-    mc->DW = DW;
-    mc->rows_alloc = mc->Pv + 2 * (MX_LDS / 128 / 16 * 16) + 2;   // read-ahead of the last workgroup: at most one LDS image of rows
-    const size_t bytes = (size_t)mc->rows_alloc * DW * 4;
-    TSR_HIP(hipMalloc(reinterpret_cast<void **>(&mc->d_bits), bytes));
-    TSR_HIP(hipMemsetAsync(mc->d_bits, 0, bytes, ctx->stream));
-    if (mc->Pv > 0) {
-        int64_t *d_tab = nullptr;
-        TSR_HIP(hipMalloc(reinterpret_cast<void **>(&d_tab), (size_t)(N + 1) * 16));
-        hipError_t e = hipMemcpyAsync(d_tab, cp->offsets.data(), (size_t)(N + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_tab + (N + 1), mc->voff.data(), (size_t)(N + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) {
-            const int64_t total = mc->Pv * DW;
-            hipLaunchKernelGGL(mx_pack_bits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, cp->d_feats, cp->Dp,
-                               d_tab, d_tab + (N + 1), N, DW, mc->Pv, mc->d_bits);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        (void)hipFree(d_tab);
-        if (e != hipSuccess) {
-            (void)hipFree(mc->d_bits);
-            mc->d_bits = nullptr;
-            tsr_set_error("TSR_MX: building the bit rows failed: %s", hipGetErrorString(e));
-            return TSR_ERR_HIP;
-        }
-    }
-    return TSR_OK;
+    return mx_build_rows(ctx, cp, mc, DW, 0, 1, nullptr);
 }
 
 // Groups (pairs of window starts), tiles of 16 groups, workgroups of at most MX_NT tiles whose frames fit the LDS image.
@@ -850,25 +853,40 @@ static int mx_corpus_plan(tsr_ctx *ctx, tsr_corpus *cp, const MxBank *mb)
         mc->d_groups = nullptr;
         mc->d_wg = nullptr;
     }
-    mc->plan_Lmin = mb->Lmin; mc->plan_ROWS = mb->ROWS; mc->plan_NR = mb->NR;
+    mc->plan_Lmin = mc->plan_ROWS = mc->plan_NR = -1;   // (set again below: a failure on the way leaves no plan behind)
     mc->plan_unsupported = false;
+    auto keep = [&](bool unsupported) {
+        mc->plan_Lmin = mb->Lmin; mc->plan_ROWS = mb->ROWS; mc->plan_NR = mb->NR;
+        mc->plan_unsupported = unsupported;
+        return unsupported ? TSR_ERR_UNSUPPORTED : TSR_OK;
+    };
+    // A tile is 16 consecutive records.  Where 16 pairs would span more rows than an LDS image holds (utterances barely longer
+    // than the filters give one pair per T rows), the tile is closed early and filled up with records that score nothing
+    // (rem = 0: no window, no frame of their own), so that every tile fits a workgroup whatever the utterance lengths are.
     std::vector<MxGroup> groups;
+    const int64_t span_max = 2 * (int64_t)mb->NR;
+    int in_tile = 0;
+    int64_t tile_v0 = 0;
     for (int64_t u = 0; u < cp->N; ++u) {
         const int64_t T = cp->offsets[(size_t)u + 1] - cp->offsets[(size_t)u];
         if (T <= 0) continue;
         const int64_t ng = (std::max<int64_t>(T - mb->Lmin + 1, 1) + 1) / 2;
         for (int64_t g = 0; g < ng; ++g) {
             const int64_t v0 = mc->voff[(size_t)u] + 2 * g, p0 = cp->offsets[(size_t)u] + 2 * g;
-            if (v0 > INT32_MAX - 4096 || groups.size() > (size_t)INT32_MAX / 32) {
-                mc->plan_unsupported = true;
-                return TSR_ERR_UNSUPPORTED;
+            if (v0 > INT32_MAX - 4096 || groups.size() > (size_t)INT32_MAX / 32) return keep(true);
+            if (in_tile == 16) in_tile = 0;
+            if (in_tile > 0 && v0 + mb->ROWS - tile_v0 > span_max) {
+                const MxGroup last = groups.back();
+                for (; in_tile < 16; ++in_tile) groups.push_back(MxGroup{last.v0, last.p0, 0, 0});
+                in_tile = 0;
             }
+            if (in_tile == 0) tile_v0 = v0;
             groups.push_back(MxGroup{(int32_t)v0, (int32_t)p0, (int32_t)std::min<int64_t>(T - 2 * g, INT32_MAX), 0});
+            ++in_tile;
         }
     }
     const int64_t n_groups = (int64_t)groups.size(), n_tiles = (n_groups + 15) / 16;
     std::vector<int4> wgs;
-    const int64_t span_max = 2 * (int64_t)mb->NR;
     auto span_end = [&](int64_t tile_last) {   // one past the last virtual row the tiles up to tile_last read
         const int64_t gl = std::min<int64_t>(n_groups, (tile_last + 1) * 16) - 1;
         return (int64_t)groups[(size_t)gl].v0 + mb->ROWS;
@@ -877,17 +895,13 @@ static int mx_corpus_plan(tsr_ctx *ctx, tsr_corpus *cp, const MxBank *mb)
         const int64_t v_lo = groups[(size_t)(t * 16)].v0;
         int64_t cnt = 0;
         while (cnt < MX_NT && t + cnt < n_tiles && span_end(t + cnt) - v_lo <= span_max) ++cnt;
-        if (cnt == 0) {   // not even one tile's frames fit (tiny utterances with long filters)
-            mc->plan_unsupported = true;
-            return TSR_ERR_UNSUPPORTED;
-        }
+        if (cnt == 0) return keep(true);   // (cannot happen: tiles are closed before they outgrow the image, and ROWS + 34 <= 2 NR)
         wgs.push_back(make_int4((int)t, (int)cnt, (int)v_lo, (int)(span_end(t + cnt - 1) - v_lo)));
         t += cnt;
     }
     for (const int4 &w : wgs)
         if ((int64_t)w.z + w.w > mc->rows_alloc) {   // (cannot happen: the slack behind the bit rows is one LDS image)
-            mc->plan_unsupported = true;
-            return TSR_ERR_UNSUPPORTED;
+            return keep(true);
         }
     mc->n_groups = (int)n_groups;
     mc->n_wg = (int)wgs.size();
@@ -898,7 +912,7 @@ static int mx_corpus_plan(tsr_ctx *ctx, tsr_corpus *cp, const MxBank *mb)
         TSR_HIP(hipMemcpyAsync(mc->d_wg, wgs.data(), wgs.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
         TSR_HIP(hipStreamSynchronize(ctx->stream));
     }
-    return TSR_OK;
+    return keep(false);
 }
 
 // TSR_FAST | TSR_MX: the maximum over the templates with its id, or (d_all) every template's scores [M][P].
@@ -934,14 +948,15 @@ int tsr_launch_mx_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, float
     MxArgs a;
     a.bits = mc->ext_bits ? mc->ext_bits : mc->d_bits; a.B = mb->d_B;
     a.n_phase = mb->n_phase; a.DWr = mc->DWr; a.bits_phase = mc->bits_phase; a.B_phase = (long long)mb->NKB * 3 * 1536; a.groups = mc->d_groups; a.wg = mc->d_wg; a.cols = mb->d_cols;
-    {   // (development override: TSR_MX_SLOWCAP)
-        const char *e = getenv("TSR_MX_SLOWCAP");
-        a.slow_cap = e ? atoi(e) : (mb->NKB * 13 + 63) / 64 / 2 + 1;
-    }
+    // (development override, read once per process: TSR_MX_SLOWCAP)
+    static const int slow_cap_env = [] { const char *e = getenv("TSR_MX_SLOWCAP"); return e ? atoi(e) : 0; }();
+    a.slow_cap = slow_cap_env > 0 ? slow_cap_env : (mb->NKB * 13 + 63) / 64 / 2 + 1;
+    a.fixed = mb->exact ? 0 : 1;
     a.scores = d_scores; a.ids = d_ids; a.all = d_all; a.P = cp->P; a.M = bank->M;
     a.kq = mb->d_kq; a.CH = mb->CH; a.nfull = mb->nfull; a.packed = mb->packed;
     a.n_groups = mc->n_groups; a.NKB = mb->NKB; a.KBF = mb->KBF; a.NR = mb->NR; a.Lmin = mb->Lmin; a.idmax = mb->idmax; a.cmax = mb->cmax;
     TSR_REQUIRE((size_t)32 * mb->CH * mb->NR <= (size_t)MX_IMAGE && (size_t)MX_NT * 7 * 1024 <= (size_t)MX_IMAGE, "TSR_MX: LDS image too large");
+    TSR_REQUIRE(2 * mb->KBF * mb->NR <= 5 * MX_WAVES * 64, "TSR_MX: more rows than the staging covers");
     const size_t lds = MX_LDS;
     a.dbg = nullptr;
 #ifdef TSR_STAMP

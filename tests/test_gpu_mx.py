@@ -61,6 +61,8 @@ def _check(tsr_hip, oracle, c, with_oracle=True, tol=TOL):
     bank = tsr_hip.Bank(c["bank"])
     s, a = bank.score(f2, offs, flags=tsr_hip.TSR_FAST | tsr_hip.TSR_MX)
     assert s.shape == (P,) and a.shape == (P,)
+    if P:                                      # (no silent service by TSR_FAST's kernels: its 16-bit sums differ from the emulation)
+        assert tsr_hip.default_ctx().get_option(tsr_hip.TSR_INFO_LAST_BANK_KERNEL) == tsr_hip.TSR_KERNEL_MX
     es, ea, vals, slack = _emulate(f2, offs, c["bank"])
     assert np.all(np.abs(s - es) <= slack + 1e-30), float(np.max(np.abs(s - es) - slack))
     if vals.shape[0] > 1 and P:
@@ -154,6 +156,58 @@ def test_mx_ragged_large_corpus(tsr_hip, oracle):
     c = synth.corpus(606, N=420, T=T, F=45, E=8, M=8, L=[28, 29, 30, 32, 32, 33, 35, 36])
     assert int(c["offsets"][-1]) >= 60000
     _check(tsr_hip, oracle, c)
+
+
+@pytest.mark.parametrize("shape", [
+    dict(N=269, F=6, E=5, M=8, L=153),      # one chunk array per parity: its rows are capped by what one staging pass covers
+    dict(N=219, F=26, E=5, M=2, L=58),      # five chunk arrays, two staged pieces per row
+    dict(N=150, F=9, E=16, M=3, L=200),     # D = 144, long filters: tiles closed early where 16 pairs would outgrow the image
+], ids=["D30", "D130", "D144"])
+def test_mx_many_short_utterances_on_narrow_rows(tsr_hip, oracle, shape):
+    """Utterances shorter than the filters still occupy rows of the LDS image (one pair each, for the tail rule), so that a
+    workgroup's frames can span thousands of rows when the rows are narrow: every one of them has to be staged (found by
+    tools/fuzz_mx.py --large: arrays longer than five pieces per thread cover were left partly unfilled).  Where 16 pairs of
+    such utterances would span more rows than the image holds, the plan closes the tile early (records that score nothing)."""
+    from tsr_hip import synth
+    rng = np.random.default_rng(shape["N"])
+    Ts = [int(x) for x in rng.integers(0, 420, size=shape["N"])]
+    c = synth.corpus(55, N=shape["N"], T=Ts, F=shape["F"], E=shape["E"], M=shape["M"], L=shape["L"])
+    _check(tsr_hip, oracle, c)
+
+
+def test_mx_sums_beyond_2_24_repeat_bit_for_bit(tsr_hip, oracle):
+    """128-tap filters on 512 features (one phase): the fixed-point sums pass 2^24, where the f32 accumulator rounds and the
+    order of the additions shows.  The bank is then scored with its K-blocks in fixed shares: three launches return the same
+    bits, the all-scores pass has the fused pass' maximum, and the result stays within the bar of the oracle (and within
+    2^-18 relative of the exact-integer emulation)."""
+    from tsr_hip import synth
+    rng = np.random.default_rng(9)
+    Ts = [int(x) for x in rng.integers(150, 420, size=24)]
+    c = synth.corpus(56, N=24, T=Ts, F=64, E=8, M=3, L=128)
+    # weights of one sign and similar size: the sums grow with the number of set taps (~ -4 * 10^7 here)
+    c["bank"] = [((-(1.0 + 0.5 * rng.random((128, 64, 8))) * (1.0 + 0.1 * m)).astype(np.float32), float(np.float32(3000.0 + 7 * m))) for m in range(3)]
+    P = int(c["offsets"][-1])
+    f2 = c["feats"].reshape(P, -1)
+    bank = tsr_hip.Bank(c["bank"])
+    dc = tsr_hip.Corpus(f2, c["offsets"])
+    runs = []
+    for _ in range(3):
+        dc.score(bank, tsr_hip.TSR_FAST | tsr_hip.TSR_MX)
+        assert tsr_hip.default_ctx().get_option(tsr_hip.TSR_INFO_LAST_BANK_KERNEL) == tsr_hip.TSR_KERNEL_MX
+        runs.append(dc.download())
+    for s_, a_ in runs[1:]:
+        assert np.array_equal(s_, runs[0][0]) and np.array_equal(a_, runs[0][1])
+    s = runs[0][0]
+    allm = dc.score_all(bank, tsr_hip.TSR_FAST | tsr_hip.TSR_MX)
+    assert np.array_equal(allm.max(0), s)
+    es, ea, vals, slack = _emulate(f2, c["offsets"], c["bank"])
+    raw = max(float(np.abs(vals[m] - np.float32(cm)).max()) * 4095 / float(np.abs(W).max()) for m, (W, cm) in enumerate(c["bank"]))
+    assert raw > 2 ** 24   # (the case is what it says: integer sums beyond the f32 mantissa)
+    assert np.all(np.abs(s - es) <= 16 * slack + 1e-30)
+    so, ao = oracle.score_corpus(c["feats"], c["offsets"], c["bank"])
+    assert rel_err(s, so) <= TOL
+    dc.close()
+    bank.close()
 
 
 def test_mx_long_utterance(tsr_hip, oracle):
