@@ -81,13 +81,14 @@ enum { TSR_EXACT = 0, TSR_FAST = 1, TSR_W24 = 2, TSR_BF16 = 4, TSR_MX = 8 };
  *              weights at four times the bf16 rate, the digits' weights 1 / 16 / 256 applied by its block scales, one
  *              f32 accumulator holding the exact integer sum).  The bank pass is a skew-free Toeplitz product
  *              (csrc/detect_mx.hip) and the fastest path for a bank of up to eight templates (BASELINE config 2;
- *              rows wider than 512 features -- config 3's part corpora -- go through the kernel in feature phases);
+ *              rows wider than 512 features -- config 3's part corpora -- go through the kernel in feature phases,
+ *              banks of more than eight templates in slices of eight, one launch each, merged in the result arrays);
  *              |error| <= 2^-13 * max|W_m| per SET tap in the worst case, unbiased -- observed 2e-5 relative on
  *              config 2 (scores of order 4 * 10^3), i.e. eight times TSR_FAST's figure and a fifth of the 1e-4 bar.
  *              Sums below 2^24 (config 2) are exact integers; beyond (wide rows) the f32 accumulator rounds at 2^-24
  *              relative per addition, in a fixed order: the same bits from launch to launch.  Max mode (scores + ids)
- *              and all-scores passes; banks of more than eight templates and filters of at most 4096 taps are served
- *              as plain TSR_FAST.  Stands alone beside TSR_FAST (not with TSR_W24 / TSR_BF16). */
+ *              and all-scores passes; filters of at most 4096 taps are served as plain TSR_FAST.  Stands alone
+ *              beside TSR_FAST (not with TSR_W24 / TSR_BF16). */
 
 typedef struct tsr_ctx tsr_ctx;       /* device + stream + scratch                 */
 typedef struct tsr_bank tsr_bank;     /* device-resident template bank             */

@@ -43,6 +43,7 @@ constexpr int MX_NT = 21;         // row tiles per workgroup (accumulators: 4 re
 constexpr int MX_WAVES = 8;
 constexpr int MX_LDS = 163840;    // the whole LDS of a CU
 constexpr int MX_MAX_KBF = 4;     // feature rows of up to 512 features
+constexpr int MX_MAX_SLICES = 32;  // banks of up to 256 templates (eight per launch)
 constexpr int MX_QMAX = 4095;     // |fixed-point weight|
 
 struct MxGroup {   // one tile row: the window starts t0 and t0 + 1 of one utterance
@@ -69,6 +70,7 @@ struct MxArgs {
     int n_groups, NKB, KBF, NR, Lmin, idmax;
     int CH, nfull, packed, M;
     int slow_cap;             // K-blocks a wave of the slower half (waves 4..7) takes at most
+    int merge;                // max mode, second and later slices of a bank of more than eight templates: keep the better of old and new
     int fixed;                // K-blocks in fixed shares (wave w: w, w + 8, ...): banks whose sums may pass 2^24, where the order of the f32 additions shows
     int n_phase, DWr;         // feature phases (rows wider than 512 features: one staging + K loop per phase, one accumulator set); dwords per bit row
     long long bits_phase, B_phase;   // dwords / bytes from one phase's bit rows / fragments to the next    // chunk arrays per frame parity; full 32-feature chunks of a row; leftover features of four tap rows share a chunk
@@ -91,6 +93,7 @@ struct MxArgs {
 
 struct MxBank {
     int KBF = 0, ROWS = 0, NKB = 0, NR = 0, Lmin = 0, Lmax = 0, idmax = 0, CH = 0, nfull = 0, packed = 0, n_phase = 1, pw = 0;
+    int n_slice = 1;          // groups of eight templates
     bool exact = true;        // no sum of the bank's weights over any set of taps reaches 2^24
     int32_t *d_kq = nullptr;
     float cmax = 0;
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
             if (a.all && ok[u] && s < grem[u] && col[g].L < (1 << 30)) a.all[(int64_t)col[g].id * a.P + gp0[u] + s] = val;
             if (g == 0 || val > bv) {
                 bv = val;
-                bm = 4 * h + g;
+                bm = col[g].id;   // (ids grow with the slot: 4 h + g + the slice's first template)
             }
         }
         const float ov = __shfl_xor(bv, 16);
@@ -528,22 +531,26 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
         }
         if (a.all) continue;
         if (ok[u] && h == 0 && s < grem[u]) {   // lanes 0..15: the first start of a pair, lanes 32..47: the second
-            a.scores[gp0[u] + s] = bv;
-            a.ids[gp0[u] + s] = bm;
+            // (merge: a later slice of a bank of more than eight templates replaces what the earlier ones left only where it
+            // is strictly better -- the lowest id keeps a tie, as within a slice)
+            if (!a.merge || bv > a.scores[gp0[u] + s]) {
+                a.scores[gp0[u] + s] = bv;
+                a.ids[gp0[u] + s] = bm;
+            }
         }
     }
     // the last pair of an utterance: the frames behind its two starts score max_m c_m (every template is in its tail
     // there).  Pairs are flagged by lanes 0..15, the whole wave then fills one flagged pair after the other.
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
-        unsigned long long todo = __ballot(ok[u] && lane < 16 && grem[u] > 2 && grem[u] < a.Lmin + 2);
+        unsigned long long todo = __ballot(ok[u] && lane < 16 && grem[u] > 2 && grem[u] < a.Lmin + 2 && (a.all || !a.merge));   // (max mode: the first slice fills the tails with the whole bank's max_m c_m)
         while (todo) {
             const int i = __builtin_ctzll(todo);
             todo &= todo - 1;
             const int bp = __builtin_amdgcn_readlane(gp0[u], i), br = __builtin_amdgcn_readlane(grem[u], i);
             for (int t = 2 + lane; t < br; t += 64) {
                 if (a.all) {
-                    for (int m = 0; m < a.M; ++m) a.all[(int64_t)m * a.P + bp + t] = a.cols[m].c;
+                    for (int m = 0; m < a.M; ++m) a.all[(int64_t)a.cols[m].id * a.P + bp + t] = a.cols[m].c;
                 } else {
                     a.scores[bp + t] = a.cmax;
                     a.ids[bp + t] = a.idmax;
@@ -597,7 +604,7 @@ void tsr_mx_corpus_free(tsr_corpus *cp)
     cp->mx = nullptr;
 }
 
-// The bank's fragments.  TSR_ERR_UNSUPPORTED: more than 8 templates, fewer than 24 K-blocks (per phase), or filters so long
+// The bank's fragments.  TSR_ERR_UNSUPPORTED: more than 256 templates, fewer than 24 K-blocks (per phase), or filters so long
 // that not even one tile's frames fit the LDS image.
 static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
 {
@@ -615,7 +622,8 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
         Dph = 32 * (int64_t)pw;
     }
     const int KBF = n_phase > 1 ? 3 : (int)((Dph + 127) / 128);   // (phases: always three staged pieces per row, pw <= 12)
-    if (M < 1 || M > 8 || KBF > MX_MAX_KBF || n_phase > 64) {
+    const int n_slice = (M + 7) / 8;   // more than eight templates: slices of eight, one launch each, merged in the result arrays
+    if (M < 1 || n_slice > MX_MAX_SLICES || KBF > MX_MAX_KBF || n_phase > 64) {
         bank->mx_unsupported = true;
         return TSR_ERR_UNSUPPORTED;
     }
@@ -652,8 +660,8 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
     TSR_HIP(hipSetDevice(ctx->device));
     MxBank *mb = new MxBank;
     mb->KBF = KBF; mb->ROWS = ROWS; mb->NKB = NKB; mb->NR = NR; mb->Lmin = Lmin; mb->Lmax = bank->Lmax;
-    mb->CH = CH; mb->nfull = nfull; mb->packed = packed; mb->n_phase = n_phase; mb->pw = pw;
-    std::vector<MxCol> cols(16);
+    mb->CH = CH; mb->nfull = nfull; mb->packed = packed; mb->n_phase = n_phase; mb->pw = pw; mb->n_slice = n_slice;
+    std::vector<MxCol> cols((size_t)16 * n_slice);
     std::vector<double> scale(M);
     std::vector<int64_t> woff(M + 1, 0);
     for (int m = 0; m < M; ++m) woff[m + 1] = woff[m] + (int64_t)bank->L[m] * D;
@@ -679,12 +687,13 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
         }
         if (std::max(pos, neg) >= 16777216.0) mb->exact = false;
     }
-    for (int n = 0; n < 16; ++n) {
-        const int m = n & 7;
-        if (m < M) cols[n] = MxCol{(float)(1.0 / scale[m]), (float)bank->c[m], bank->L[m], m};
-        else cols[n] = MxCol{0.0f, -INFINITY, 1 << 30, 0x7ffffffe};
-    }
-    std::vector<unsigned char> Bf((size_t)n_phase * NKB * 3 * 1536, 0);
+    for (int sl = 0; sl < n_slice; ++sl)
+        for (int n = 0; n < 16; ++n) {
+            const int m = 8 * sl + (n & 7);
+            if (m < M) cols[(size_t)16 * sl + n] = MxCol{(float)(1.0 / scale[m]), (float)bank->c[m], bank->L[m], m};
+            else cols[(size_t)16 * sl + n] = MxCol{0.0f, -INFINITY, 1 << 30, 0x7ffffffe};
+        }
+    std::vector<unsigned char> Bf((size_t)n_slice * n_phase * NKB * 3 * 1536, 0);   // [slice][phase][K-block][digit]
     std::vector<int32_t> kq((size_t)NKB * 4);
     for (int kb = 0; kb < NKB; ++kb)
         for (int q = 0; q < 4; ++q) {
@@ -692,10 +701,11 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
             const int row = cr.rho >= 0 ? (cr.rho >> 1) : cr.rho == -1 ? cr.k0 : 0;   // rows behind the pair's first frame row
             kq[(size_t)kb * 4 + q] = ((cr.plane * CH + cr.c) * NR + row) << 4;
         }
+    for (int sl = 0; sl < n_slice; ++sl)
     for (int ph = 0; ph < n_phase; ++ph)
     for (int kb = 0; kb < NKB; ++kb) {
         for (int lane = 0; lane < 64; ++lane) {
-            const int n = lane & 15, q = lane >> 4, s = n >> 3, m = n & 7;
+            const int n = lane & 15, q = lane >> 4, s = n >> 3, m = 8 * sl + (n & 7);
             const ChunkRef &cr = refs[(size_t)kb * 4 + q];
             uint32_t str[3][6] = {{0}};
             if (m < M && cr.rho != -2) {
@@ -729,7 +739,7 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
                 }
             }
             for (int l = 0; l < 3; ++l) {
-                unsigned char *dst = Bf.data() + (((size_t)ph * NKB + kb) * 3 + l) * 1536;
+                unsigned char *dst = Bf.data() + ((((size_t)sl * n_phase + ph) * NKB + kb) * 3 + l) * 1536;
                 memcpy(dst + lane * 16, &str[l][0], 16);
                 memcpy(dst + 1024 + lane * 8, &str[l][4], 8);
             }
@@ -964,8 +974,15 @@ int tsr_launch_mx_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, float
     TSR_HIP(hipMalloc(reinterpret_cast<void **>(&a.dbg), nst * 8));
     TSR_HIP(hipMemsetAsync(a.dbg, 0, nst * 8, ctx->stream));
 #endif
-    void *kargs[] = {&a};
-    TSR_HIP(hipLaunchKernel(kern, dim3((unsigned)mc->n_wg), dim3(MX_WAVES * 64), kargs, lds, ctx->stream));
+    // one launch per slice of eight templates; the second and later ones merge into the result arrays (max mode)
+    for (int sl = 0; sl < mb->n_slice; ++sl) {
+        a.B = mb->d_B + (size_t)sl * mb->n_phase * mb->NKB * 3 * 1536;
+        a.cols = mb->d_cols + 16 * sl;
+        a.M = std::min(8, bank->M - 8 * sl);
+        a.merge = sl > 0;
+        void *kargs[] = {&a};
+        TSR_HIP(hipLaunchKernel(kern, dim3((unsigned)mc->n_wg), dim3(MX_WAVES * 64), kargs, lds, ctx->stream));
+    }
 #ifdef TSR_STAMP
     if (const char *path = getenv("TSR_STAMP_OUT")) {
         std::vector<unsigned long long> h(nst);

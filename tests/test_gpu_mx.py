@@ -210,6 +210,44 @@ def test_mx_sums_beyond_2_24_repeat_bit_for_bit(tsr_hip, oracle):
     bank.close()
 
 
+@pytest.mark.parametrize("shape", [
+    dict(N=6, T=[200, 90, 33, 140, 64, 31], F=45, E=8, M=9, L=32),                                  # nine templates: a slice of eight and a slice of one
+    dict(N=5, T=[120, 61, 200, 47, 90], F=45, E=8, M=20, L=[20 + (3 * i) % 17 for i in range(20)]),   # three slices, ragged filters
+    dict(N=30, T=200, F=45, E=8, M=64, L=32),                                                       # config 4's bank on a small corpus: eight slices
+], ids=["M9", "M20_ragged", "M64"])
+def test_mx_banks_of_more_than_eight_templates(tsr_hip, oracle, shape):
+    """More than eight templates go through the kernel in slices of eight, one launch each; the later launches keep the
+    better of what is there and what they found (ties: the lower id, i.e. the earlier slice).  Against the emulation and
+    the oracle, ids included; the all-scores pass writes every template's row."""
+    from tsr_hip import synth
+    c = synth.corpus(91, **shape)
+    s, a = _check(tsr_hip, oracle, c)
+    P = int(c["offsets"][-1])
+    f2 = c["feats"].reshape(P, -1)
+    bank = tsr_hip.Bank(c["bank"])
+    dc = tsr_hip.Corpus(f2, c["offsets"])
+    allm = dc.score_all(bank, tsr_hip.TSR_FAST | tsr_hip.TSR_MX)
+    assert tsr_hip.default_ctx().get_option(tsr_hip.TSR_INFO_LAST_BANK_KERNEL) == tsr_hip.TSR_KERNEL_MX
+    es, ea, vals, slack = _emulate(f2, c["offsets"], c["bank"])
+    assert allm.shape == vals.shape and np.all(np.abs(allm - vals) <= slack[None, :] + 1e-30)
+    assert np.array_equal(allm.max(0), s)
+    assert np.array_equal(a, np.argmax(allm, axis=0))           # (first maximum = lowest id, across the slices too)
+    dc.close()
+    bank.close()
+
+
+def test_mx_ties_across_slices_go_to_the_lowest_id(tsr_hip, oracle):
+    """Templates 1 and 9 are the same filter: wherever they are the best, the id is 1 (the later slice replaces a score only
+    where it is strictly better)."""
+    from tsr_hip import synth
+    c = synth.corpus(92, N=4, T=[120, 64, 200, 90], F=45, E=8, M=12, L=32)
+    bk = list(c["bank"])
+    bk[9] = bk[1]
+    c["bank"] = tuple(bk)
+    s, a = _check(tsr_hip, oracle, c)
+    assert not np.any(a == 9) and np.any(a == 1)
+
+
 def test_mx_long_utterance(tsr_hip, oracle):
     from tsr_hip import synth
     c = synth.corpus(70, N=2, T=[30001, 777], F=45, E=8, M=6, L=[32, 41, 36, 33, 40, 38])
@@ -217,15 +255,15 @@ def test_mx_long_utterance(tsr_hip, oracle):
 
 
 def test_mx_requests_outside_its_envelope_are_served_as_fast(tsr_hip, oracle):
-    """More than eight templates and short filters fall to TSR_FAST's int8 kernels: same results as plain TSR_FAST, bit
-    for bit."""
+    """Short filters (fewer than 24 K-blocks) fall to TSR_FAST's int8 kernels: same results as plain TSR_FAST, bit for bit."""
     from tsr_hip import synth
-    for shape in (dict(N=3, T=[90, 140, 60], F=45, E=8, M=9, L=32), dict(N=3, T=[40, 50, 30], F=6, E=5, M=3, L=9)):
+    for shape in (dict(N=3, T=[40, 50, 30], F=6, E=5, M=3, L=9), dict(N=2, T=[70, 90], F=16, E=8, M=9, L=20)):
         c = synth.corpus(31, **shape)
         P = int(c["offsets"][-1])
         f2 = c["feats"].reshape(P, -1)
         bank = tsr_hip.Bank(c["bank"])
         s, a = bank.score(f2, c["offsets"], flags=tsr_hip.TSR_FAST | tsr_hip.TSR_MX)
+        assert tsr_hip.default_ctx().get_option(tsr_hip.TSR_INFO_LAST_BANK_KERNEL) != tsr_hip.TSR_KERNEL_MX
         sf, af = bank.score(f2, c["offsets"], flags=tsr_hip.TSR_FAST)
         assert np.array_equal(s, sf) and np.array_equal(a, af)
         bank.close()

@@ -43,7 +43,7 @@ for case in range(n_cases):
         sf, af = bank.score(f2, c["offsets"], flags=tsr_hip.TSR_FAST)
         if not (np.array_equal(s, sf) and np.array_equal(a, af)):
             msg += " fallback != TSR_FAST"
-        if P and M <= 8 and min(Ls) * D > 4096 and (D <= 512 or max(Ls) >= 12):   # (wide rows: at least 24 K-blocks per phase)
+        if P and min(Ls) * D > 4096 and (D <= 512 or max(Ls) >= 12):   # (wide rows: at least 24 K-blocks per phase)
             msg += " inside the envelope but not served by the MX kernel"
     else:
         served += 1
