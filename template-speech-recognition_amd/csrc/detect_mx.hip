@@ -249,21 +249,24 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
     // slots; at most 2 * KBF * NR <= 2496 pieces = five per thread
     u32x4 piece[5];
     int dst[5], cpiece[5];
+    bool inside[5];
     int tidp = tid;
     if constexpr (PHASES) asm volatile("" : "+v"(tidp));   // (keeps the staging addresses from being hoisted out of the phase loop, where they would be spilled)
+    // Every thread takes five pieces: past the last one it takes the last one again (the same bits to the same slot), and a
+    // row past the last frame is loaded from the first one and zeroed on the way -- loads and stores are unconditional, i.e.
+    // straight-line code, in which the compiler's wait counts are exact: the first piece is expanded while the others are
+    // still on their way (with branches around the pieces every one of them waited for all five).
+    const int n_piece = 2 * KBF * nrows;
 #pragma unroll
     for (int it = 0; it < 5; ++it) {
-        const int idx = tidp + it * (MX_WAVES * 64);
+        const int idx = min(tidp + it * (MX_WAVES * 64), n_piece - 1);
         const int pass = idx / nrows, r = idx - pass * nrows;
         const int plane = pass & 1, kbf = pass >> 1;
         const int fr = 2 * r + plane;
-        piece[it] = u32x4{0, 0, 0, 0};
-        dst[it] = -1;
+        inside[it] = fr < nfr;
         cpiece[it] = kbf;
-        if (pass < 2 * KBF) {
-            dst[it] = ((plane * CH + 4 * kbf) * NR + r) << 4;
-            if (fr < nfr) piece[it] = *reinterpret_cast<const u32x4 *>(bits + (size_t)(v_lo + fr) * DWr + 4 * kbf);
-        }
+        dst[it] = ((plane * CH + 4 * kbf) * NR + r) << 4;
+        piece[it] = *reinterpret_cast<const u32x4 *>(bits + (size_t)(v_lo + (inside[it] ? fr : 0)) * DWr + 4 * kbf);
     }
     const unsigned char *bp = Bph + (size_t)wave * (3 * 1536) + lane * 16;
     i32x4 b4[3];
@@ -287,10 +290,9 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
     // fragments use the same order), which makes a chunk four shift-and-mask pairs
 #pragma unroll
     for (int it = 0; it < 5; ++it) {
-        if (dst[it] < 0) continue;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const unsigned x = piece[it][q];
+            const unsigned x = inside[it] ? piece[it][q] : 0u;
             const u32x4 o = {(x << 1) & 0x22222222u, x & 0x22222222u, (x >> 1) & 0x22222222u, (x >> 2) & 0x22222222u};
             if (FULL || 4 * cpiece[it] + q < CH) *reinterpret_cast<u32x4 *>(lds + dst[it] + ((q * NR) << 4)) = o;
         }
