@@ -1,5 +1,5 @@
-// detect_mx.hip -- TSR_FAST | TSR_MX: the bank pass of a small template bank (M <= 8) on narrow feature rows as a
-// skew-free Toeplitz product on the block-scaled matrix instruction v_mfma_scale_f32_16x16x128_f8f6f4.
+// detect_mx.hip -- TSR_FAST | TSR_MX: the bank pass as a skew-free Toeplitz product on the block-scaled matrix
+// instruction v_mfma_scale_f32_16x16x128_f8f6f4, eight templates per launch.
 // (reference: compute_likelihood_linear_filter.pyx:162-175 for the sums, get_train_data.py:962-992 for the bank epilogue)
 //
 // Formulation.  A tile is 16 *pairs* of window starts: pair i stands for the starts t0_i and t0_i + 1 (t0_i even
@@ -13,19 +13,25 @@
 // Operands.  X is binary, so it is an exact fp4 (e2m1) operand: nibble 0x2 = 1.0.  The weights are fixed point with a
 // per-template scale, |q| <= 4095, split into three radix-16 digits in -16 .. 16, each an exact fp6 (e2m3) value
 // digit / 8; the instruction's block scales (E8M0, one per lane and 32 K-elements) carry 2^3, 2^7 and 2^11, so the three
-// limb products meet in ONE f32 accumulator as the exact integer sum (all partial sums are integers below 2^24).
+// limb products meet in ONE f32 accumulator as the exact integer sum (exact while it stays below 2^24; banks that can go
+// beyond take their K-blocks in fixed shares, so that the rounding is the same in every launch).
 // fp4 x fp6 issues at four times the bf16 rate (MI355X_MICROARCH.md; tools/ubench/mx_probe.hip measured 16.4 cycles per
 // instruction and SIMD), three limbs therefore cost 0.75 of the two int8 limbs of the tap-pair kernel -- at 13 instead of
 // 16 bits of weight (include/tsr.h says what that means for the error).
 //
-// Work split.  One workgroup per CU takes MX_NT = 21 row tiles (672 window starts) and holds ALL their frames in LDS
+// Work split.  One workgroup per CU takes MX_NT = 21 tiles (672 window starts) and holds ALL their frames in LDS
 // as nibbles (expanded from the corpus' resident bit rows: 48 B per frame from HBM instead of 368), column-major:
-// [frame parity][16-byte chunk of the row][row] so that the 16 rows of an A fragment are 16 consecutive 16-byte slots
-// (conflict-free ds_read_b128 at any alignment when the rows per column are a multiple of 16) and a fragment's address
-// is (per-lane tile base) + (wave-uniform offset of the K-block).  The eight waves split K: wave w owns the K-blocks
-// w, w + 8, ... (a K-block = 128 features of one tap row), streams their B fragments from L2 straight into registers
-// (456 KB per workgroup, once) and walks all 21 tiles with them.  The eight partial accumulators of a tile meet once, at the
-// end, through LDS; the tile's owner applies scale, tail rule, + c and the max / first arg-max over templates.
+// [frame parity][16-byte chunk of the row][row] so that the 16 columns of a B fragment are 16 consecutive 16-byte slots
+// (conflict-free ds_read_b128 at any alignment when the rows per array are a multiple of 16) and a fragment's address
+// is (per-lane tile base) + (offset of the K-block's K-quarter, from a table).  The eight waves split K: a K-block (any
+// four 32-feature chunks: features of a tap row, or the leftover features of four tap rows packed into one chunk) goes to
+// one wave -- drawn from a counter in LDS, or in fixed shares -- which streams its three digit fragments from L2 straight
+// into registers and walks all 21 tiles with them.  The eight partial accumulators of a tile meet once, at the end,
+// through LDS; the tile's owner applies scale, tail rule, + c and the max / first arg-max over templates.
+//
+// Wider forms of the same kernel: rows of more than 512 features go through staging and K loop once per feature phase
+// with one accumulator set (PHASES; the phases are those of the corpora's resident bit form); banks of more than eight
+// templates take one launch per slice of eight, the later ones merging into the result arrays.
 #include <algorithm>
 #include <cmath>
 
@@ -58,22 +64,22 @@ struct MxCol {     // one of the 16 columns: (shift s = n >> 3, template m = n &
 };
 struct MxArgs {
     const uint32_t *bits;     // [rows][DW] resident bit rows at virtual positions
-    const unsigned char *B;   // [NKB][3 limbs][1536]: 64 lanes x 16 B, then 64 lanes x 8 B
+    const unsigned char *B;   // this launch's slice: [phase][NKB][3 digits][1536]: 64 lanes x 16 B, then 64 lanes x 8 B
     const MxGroup *groups;
     const int4 *wg;           // per workgroup: first tile, tiles, first virtual row, rows to stage
-    const MxCol *cols;        // [16]
+    const MxCol *cols;        // [16] of this launch's slice
     float *scores;
     int32_t *ids;
     float *all;               // all-scores pass: [M][P] per-template scores instead of the maximum (scores / ids unused)
     int64_t P;
     const int32_t *kq;        // [NKB][4] LDS byte offset of the chunk that feeds K-quarter q of K-block kb (frame row 0 of a pair)
     int n_groups, NKB, KBF, NR, Lmin, idmax;
-    int CH, nfull, packed, M;
+    int CH, nfull, packed, M;   // chunk arrays per frame parity; full 32-feature chunks of a row; leftover features of four tap rows share a chunk; templates of this launch
     int slow_cap;             // K-blocks a wave of the slower half (waves 4..7) takes at most
     int merge;                // max mode, second and later slices of a bank of more than eight templates: keep the better of old and new
     int fixed;                // K-blocks in fixed shares (wave w: w, w + 8, ...): banks whose sums may pass 2^24, where the order of the f32 additions shows
     int n_phase, DWr;         // feature phases (rows wider than 512 features: one staging + K loop per phase, one accumulator set); dwords per bit row
-    long long bits_phase, B_phase;   // dwords / bytes from one phase's bit rows / fragments to the next    // chunk arrays per frame parity; full 32-feature chunks of a row; leftover features of four tap rows share a chunk
+    long long bits_phase, B_phase;   // dwords / bytes from one phase's bit rows / fragments to the next
     float cmax;
     unsigned long long *dbg;  // -DTSR_STAMP builds only: [workgroup][wave][16] s_memtime stamps
 };
