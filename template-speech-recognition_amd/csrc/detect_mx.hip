@@ -115,6 +115,7 @@ struct MxCorpus {   // derived forms of a corpus: bit rows (once), the tile plan
     int64_t Pv = 0, rows_alloc = 0;
     std::vector<int64_t> voff;
     int plan_Lmin = -1, plan_ROWS = -1, plan_NR = -1;
+    int plan_target = MX_NT;   // tiles per workgroup the plan aimed at (MX_NT when the corpus fits one round)
     MxGroup *d_groups = nullptr;
     int4 *d_wg = nullptr;
     int n_groups = 0, n_wg = 0;
@@ -192,8 +193,10 @@ constexpr int MX_DEPTH = 7;                       // A fragments in flight per w
 static_assert(MX_NT % MX_DEPTH == 0 && MX_NT % 3 == 0, "the fragment ring must line up across K-blocks: tile j lives in A[j % MX_DEPTH]");
 
 // FULL: the row has exactly 4 KBF chunk arrays (every 16-byte piece of a bit row fills four of them: no per-chunk checks)
-// PHASES: rows wider than 512 features, staged and multiplied in feature phases (only <3, true, true> is built)
-template <int KBF, bool FULL, bool PHASES = false>
+// PHASES: rows wider than 512 features, staged and multiplied in feature phases (only <3, true, true, .> is built)
+// PARTIAL: the launch's workgroups hold fewer than MX_NT tiles (a corpus spread over more than one round of workgroups):
+// the matrix work of absent tile groups is skipped -- a branch per tile group, which costs full workgroups ~4 %, hence a variant
+template <int KBF, bool FULL, bool PHASES = false, bool PARTIAL = false>
 __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -411,21 +414,25 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
                 if ((j / 3) & 1) n2[j / 6] = *reinterpret_cast<const i32x2 *>(nb + 1024 - lane * 8);
                 else n4[j / 6] = *reinterpret_cast<const i32x4 *>(nb);
             }
-            i32x8 Af[3];
+            // (PARTIAL: a workgroup skips the matrix work of the tile groups it does not have; the ring below keeps turning: its
+            // reads are cheap and harmless)
+            if (!PARTIAL || j == 0 || j < nt) {
+                i32x8 Af[3];
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const i32x4 x = A[(j + u) % MX_DEPTH];
-                Af[u] = i32x8{x[0], x[1], x[2], x[3], 0, 0, 0, 0};
+                for (int u = 0; u < 3; ++u) {
+                    const i32x4 x = A[(j + u) % MX_DEPTH];
+                    Af[u] = i32x8{x[0], x[1], x[2], x[3], 0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    acc[j + u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(B[0], Af[u], acc[j + u], 2, 4, 0, (int)0x82828282u, 0, 0x7f7f7f7f);
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    acc[j + u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(B[1], Af[u], acc[j + u], 2, 4, 0, (int)0x86868686u, 0, 0x7f7f7f7f);
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    acc[j + u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(B[2], Af[u], acc[j + u], 2, 4, 0, (int)0x8a8a8a8au, 0, 0x7f7f7f7f);
             }
-#pragma unroll
-            for (int u = 0; u < 3; ++u)
-                acc[j + u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(B[0], Af[u], acc[j + u], 2, 4, 0, (int)0x82828282u, 0, 0x7f7f7f7f);
-#pragma unroll
-            for (int u = 0; u < 3; ++u)
-                acc[j + u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(B[1], Af[u], acc[j + u], 2, 4, 0, (int)0x86868686u, 0, 0x7f7f7f7f);
-#pragma unroll
-            for (int u = 0; u < 3; ++u)
-                acc[j + u] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(B[2], Af[u], acc[j + u], 2, 4, 0, (int)0x8a8a8a8au, 0, 0x7f7f7f7f);
             // (behind the group's matrix instructions, which read the ring slots these reads refill: no copies of the slots)
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
@@ -472,6 +479,7 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
 #pragma unroll
     for (int j = 0; j < MX_NT; ++j) {
         const int owner = j & 7;
+        if (PARTIAL && j >= nt) continue;   // (nobody reads the sums of a tile the workgroup does not have)
         if (wave != owner) {
             const int r = wave - (wave > owner ? 1 : 0);
             *reinterpret_cast<f32x4 *>(lds + ((size_t)(j * 7 + r) << 10) + lane * 16) = acc[j];
@@ -909,13 +917,31 @@ static int mx_corpus_plan(tsr_ctx *ctx, tsr_corpus *cp, const MxBank *mb)
         const int64_t gl = std::min<int64_t>(n_groups, (tile_last + 1) * 16) - 1;
         return (int64_t)groups[(size_t)gl].v0 + mb->ROWS;
     };
-    for (int64_t t = 0; t < n_tiles;) {
-        const int64_t v_lo = groups[(size_t)(t * 16)].v0;
-        int64_t cnt = 0;
-        while (cnt < MX_NT && t + cnt < n_tiles && span_end(t + cnt) - v_lo <= span_max) ++cnt;
-        if (cnt == 0) return keep(true);   // (cannot happen: tiles are closed before they outgrow the image, and ROWS + 34 <= 2 NR)
-        wgs.push_back(make_int4((int)t, (int)cnt, (int)v_lo, (int)(span_end(t + cnt - 1) - v_lo)));
-        t += cnt;
+    // Tiles per workgroup.  A launch takes as long as its slowest CU: with one workgroup per CU and round, the tiles are
+    // spread evenly over (CUs x rounds) workgroups instead of filling each to MX_NT -- 5438 tiles are two rounds of 11 per
+    // workgroup (512 slots), not one round of 21 and a second one for the three workgroups that did not fit (which costs a
+    // whole round: measured 44 vs 24 us at config 2's size with Lmin = 28).  Where the image's span cuts workgroups short,
+    // the count can still exceed the slots: one more round, smaller shares, until it fits.
+    const int64_t n_cu = std::max(1, ctx->cus);
+    int64_t rounds = std::max<int64_t>(1, (n_tiles + n_cu * MX_NT - 1) / (n_cu * MX_NT));
+    for (;; ++rounds) {
+        const int64_t target = std::min<int64_t>(MX_NT, std::max<int64_t>(1, (n_tiles + n_cu * rounds - 1) / (n_cu * rounds)));
+        wgs.clear();
+        bool stuck = false;
+        for (int64_t t = 0; t < n_tiles;) {
+            const int64_t v_lo = groups[(size_t)(t * 16)].v0;
+            int64_t cnt = 0;
+            while (cnt < target && t + cnt < n_tiles && span_end(t + cnt) - v_lo <= span_max) ++cnt;
+            if (cnt == 0) {   // (cannot happen: tiles are closed before they outgrow the image, and ROWS + 34 <= 2 NR)
+                stuck = true;
+                break;
+            }
+            wgs.push_back(make_int4((int)t, (int)cnt, (int)v_lo, (int)(span_end(t + cnt - 1) - v_lo)));
+            t += cnt;
+        }
+        if (stuck) return keep(true);
+        mc->plan_target = (int)target;
+        if ((int64_t)wgs.size() <= n_cu * rounds || target == 1) break;
     }
     for (const int4 &w : wgs)
         if ((int64_t)w.z + w.w > mc->rows_alloc) {   // (cannot happen: the slack behind the bit rows is one LDS image)
@@ -949,18 +975,21 @@ int tsr_launch_mx_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, float
     const MxCorpus *mc = mxc(cp);
     if (mc->n_wg == 0) return TSR_OK;
     const bool full = mb->CH == 4 * mb->KBF;
+    const bool partial = mc->plan_target < MX_NT - 2;   // (most workgroups a good deal short of MX_NT tiles: see the plan)
     const void *kern = nullptr;
+#define MX_KERN(K, F, P) (partial ? reinterpret_cast<const void *>(mx_bank_kernel<K, F, P, true>) : reinterpret_cast<const void *>(mx_bank_kernel<K, F, P, false>))
     switch (mb->n_phase > 1 ? 0 : mb->KBF * 2 + (full ? 1 : 0)) {
-    case 0: kern = reinterpret_cast<const void *>(mx_bank_kernel<3, true, true>); break;
-    case 2: kern = reinterpret_cast<const void *>(mx_bank_kernel<1, false>); break;
-    case 3: kern = reinterpret_cast<const void *>(mx_bank_kernel<1, true>); break;
-    case 4: kern = reinterpret_cast<const void *>(mx_bank_kernel<2, false>); break;
-    case 5: kern = reinterpret_cast<const void *>(mx_bank_kernel<2, true>); break;
-    case 6: kern = reinterpret_cast<const void *>(mx_bank_kernel<3, false>); break;
-    case 7: kern = reinterpret_cast<const void *>(mx_bank_kernel<3, true>); break;
-    case 8: kern = reinterpret_cast<const void *>(mx_bank_kernel<4, false>); break;
-    default: kern = reinterpret_cast<const void *>(mx_bank_kernel<4, true>); break;
+    case 0: kern = MX_KERN(3, true, true); break;
+    case 2: kern = MX_KERN(1, false, false); break;
+    case 3: kern = MX_KERN(1, true, false); break;
+    case 4: kern = MX_KERN(2, false, false); break;
+    case 5: kern = MX_KERN(2, true, false); break;
+    case 6: kern = MX_KERN(3, false, false); break;
+    case 7: kern = MX_KERN(3, true, false); break;
+    case 8: kern = MX_KERN(4, false, false); break;
+    default: kern = MX_KERN(4, true, false); break;
     }
+#undef MX_KERN
     // (per launch: the attribute belongs to the function on the CURRENT device, and a process may hold several contexts)
     TSR_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS));
     MxArgs a;
