@@ -323,6 +323,46 @@ def long_corpus(ctx, corpus, bank, flags, times=10):
             "what": "config 2's corpus %d times over in one launch: prologue and launch amortised %dx" % (times, times)}
 
 
+def two_streams(corpus, flags, device, copies=48, passes=12):
+    """Independent corpora dealt round-robin to two contexts (= two HIP streams) of the device: workgroups of the next
+    launch start on CUs as those of the running one retire, so the serial phases of a launch (staging, exchange, finish,
+    the launch itself) overlap with the other stream's matrix work.  Whole-pipeline throughput by the wall clock, beside
+    the same loop on one stream (tools/time_streams.py: 23.8 -> 21.2 us per launch; two rank processes on one GPU reach
+    the same, profiles/r04_selflaunch_2rank_rehearsal.json); never part of `value` (the headline keeps one launch at a
+    time, so that its kernel time is what rocprofv3 shows per kernel and `roofline.achieved` needs no concurrency factor)."""
+    frames = int(corpus["offsets"][-1])
+    ctxs = [tsr_hip.Context(device) for _ in range(2)]
+    banks = [tsr_hip.Bank(corpus["bank"], ctx=x) for x in ctxs]
+    reps = [[tsr_hip.Corpus(corpus["feats"], corpus["offsets"], ctx=x) for _ in range(copies)] for x in ctxs]
+
+    def run(streams):
+        for s in streams:
+            for cp in reps[s]:
+                cp.score(banks[s], flags)
+        for x in ctxs:
+            x.sync()
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            for i in range(copies):
+                for s in streams:
+                    reps[s][i].score(banks[s], flags)
+        for x in ctxs:
+            x.sync()
+        return (time.perf_counter() - t0) / (passes * copies * len(streams))
+    one, two = run([0]), run([0, 1])
+    a, b = reps[0][0].download(), reps[1][copies - 1].download()
+    same = bool(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]))
+    for r in reps:
+        for cp in r:
+            cp.close()
+    for bk in banks:
+        bk.close()
+    return {"streams": 2, "copies_per_stream": copies, "us_per_launch_one_stream_wall": one * 1e6, "us_per_launch_two_streams_wall": two * 1e6,
+            "frames_per_s": frames / two, "speedup_over_one_stream": one / two, "hbm_gbs_alg": ALG_BYTES_PER_FRAME * frames / two / 1e9,
+            "frac_of_hbm_peak": ALG_BYTES_PER_FRAME * frames / two / 1e9 / HBM_PEAK_GBS, "first_and_last_copy_score_alike": same,
+            "what": "config 2, every launch on its own device-resident copy, launches dealt to two streams (wall clock over %d launches)" % (2 * passes * copies)}
+
+
 def time_launches(ctx, replicas, bank, flags, steps):
     """`steps` passes over the replica list -> (ms per launch by hipEvents on the launch stream, wall s)."""
     ctx.sync()
@@ -672,6 +712,7 @@ def main():
             out["configs"] = {"config3": config3(ctx, corpus, flags)}
             if args.mode in ("fast", "mx"):
                 out["configs"]["config2_x10_one_launch"] = long_corpus(ctx, corpus, bank, flags)
+                out["configs"]["config2_two_streams"] = two_streams(corpus, flags, int(os.environ.get("TSR_DEVICE", local_rank)))
         if world == 1 and args.extras:
             out["extras"] = extras(ctx, corpus, bank, flags)
             out["extras"]["cpu_allcores"] = allcores
