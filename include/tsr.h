@@ -91,8 +91,9 @@ enum { TSR_EXACT = 0, TSR_FAST = 1, TSR_W24 = 2, TSR_BF16 = 4, TSR_MX = 8 };
  *              beside TSR_FAST (not with TSR_W24 / TSR_BF16).  A request for this kernel, not a choice of the faster
  *              one: it pays M x (Lmax + 1) tap rows and whole rounds of workgroups (one per CU, 672 window starts
  *              each), so it is the faster for banks of near-equal filter lengths (config 2: 24 vs 33 us per 1000
- *              utterances; 64 templates of 32 taps: 183 vs 194 us) and the slower for ragged banks of many templates
- *              (config 4's L_m = 24 .. 48: 0.43 vs 0.37 ms per 1250 utterances). */
+ *              utterances; 64 templates of 32 taps: 183 vs 194 us; config 4's 64 templates of 24 .. 48 taps, dealt to
+ *              the slices by length: 0.36 vs 0.38 ms per 1250 utterances) and the slower for a ragged bank of eight
+ *              templates or fewer (one slice pays its longest filter: L_m = 28 .. 36: 39 vs 33 us). */
 
 typedef struct tsr_ctx tsr_ctx;       /* device + stream + scratch                 */
 typedef struct tsr_bank tsr_bank;     /* device-resident template bank             */

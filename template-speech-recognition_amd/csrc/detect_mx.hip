@@ -98,8 +98,10 @@ struct MxArgs {
 #endif
 
 struct MxBank {
-    int KBF = 0, ROWS = 0, NKB = 0, NR = 0, Lmin = 0, Lmax = 0, idmax = 0, CH = 0, nfull = 0, packed = 0, n_phase = 1, pw = 0;
+    int KBF = 0, ROWS = 0, NR = 0, Lmin = 0, Lmax = 0, idmax = 0, CH = 0, nfull = 0, packed = 0, n_phase = 1, pw = 0;
     int n_slice = 1;          // groups of eight templates
+    std::vector<int> slice_NKB;             // K-blocks of a slice (its longest filter + 1 tap rows)
+    std::vector<size_t> slice_kq, slice_B;  // where the slice's offset table (ints) / fragments (bytes) begin
     bool exact = true;        // no sum of the bank's weights over any set of taps reaches 2^24
     int32_t *d_kq = nullptr;
     float cmax = 0;
@@ -548,8 +550,10 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
         if (a.all) continue;
         if (ok[u] && h == 0 && s < grem[u]) {   // lanes 0..15: the first start of a pair, lanes 32..47: the second
             // (merge: a later slice of a bank of more than eight templates replaces what the earlier ones left only where it
-            // is strictly better -- the lowest id keeps a tie, as within a slice)
-            if (!a.merge || bv > a.scores[gp0[u] + s]) {
+            // is better -- the lowest id keeps a tie, as within a slice)
+            // (slices are dealt by filter length, so ids interleave: an equal score keeps the lower id)
+            const float old = a.merge ? a.scores[gp0[u] + s] : 0.0f;
+            if (!a.merge || bv > old || (bv == old && bm < a.ids[gp0[u] + s])) {
                 a.scores[gp0[u] + s] = bv;
                 a.ids[gp0[u] + s] = bm;
             }
@@ -645,7 +649,6 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
     }
     int Lmin = bank->L[0];
     for (int m = 0; m < M; ++m) Lmin = std::min(Lmin, bank->L[m]);
-    const int ROWS = bank->Lmax + 1;
     // Chunks (32 features of one frame = 16 bytes of nibbles): a row has nfull full ones and, for D % 32 != 0, one that is
     // partly filled.  Up to eight leftover features are not worth a chunk per tap row: the leftovers of FOUR tap rows of one
     // frame parity (rho, rho + 2, rho + 4, rho + 6) share a chunk (D = 360: 33 x 11 + 9 = 372 chunks = 93 K-blocks instead of
@@ -660,22 +663,22 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
     // a workgroup of short utterances can fill in one staging pass)
     const int NR = std::min(MX_IMAGE / (32 * CH), 5 * MX_WAVES * 64 / (2 * KBF)) / 16 * 16;
     struct ChunkRef { int plane, c, rho, k0; };                // c < nfull: features 32 c .. of tap row rho; c == nfull && packed: leftovers of
-    std::vector<ChunkRef> refs;                                // the tap rows plane + 2 (k0 .. k0 + 3); c == nfull && !packed: the partly filled chunk
-    for (int plane = 0; plane < 2; ++plane) {
-        for (int rho = plane; rho < ROWS; rho += 2)
-            for (int c = 0; c < (packed ? nfull : CHw); ++c) refs.push_back(ChunkRef{plane, c, rho, 0});
-        if (packed)
-            for (int k0 = 0; plane + 2 * k0 < ROWS; k0 += 4) refs.push_back(ChunkRef{plane, nfull, -1, k0});
-    }
-    const int NKB = (int)((refs.size() + 3) / 4);
-    while ((int)refs.size() < 4 * NKB) refs.push_back(ChunkRef{0, 0, -2, 0});   // filler: zero weights, any valid chunk
-    if (ROWS + 34 > 2 * NR || NKB < 3 * MX_WAVES) {   // (a tile of one long utterance spans 32 + ROWS frames; every wave starts with three K-blocks)
+                                                               // the tap rows plane + 2 (k0 .. k0 + 3); c == nfull && !packed: the partly filled chunk
+    const int ROWS = bank->Lmax + 1;                           // (the plan's: the longest filter of the whole bank)
+    if (ROWS + 34 > 2 * NR) {   // (a tile of one long utterance spans 32 + ROWS frames)
         bank->mx_unsupported = true;
         return TSR_ERR_UNSUPPORTED;
     }
+    // Slices of eight templates.  A slice pays for ITS longest filter (K runs over Lmax_slice + 1 tap rows), so the templates
+    // are dealt to the slices by length -- the eight shortest, the next eight, ... -- and ordered by id inside a slice
+    // (config 4: L_m = 24 .. 48 over 64 templates: 38.5 tap rows on average instead of 49).  One slice: the bank as it is.
+    std::vector<int> order(M);
+    for (int m = 0; m < M; ++m) order[m] = m;
+    if (n_slice > 1) std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return bank->L[x] < bank->L[y]; });
+    for (int sl = 0; sl < n_slice; ++sl) std::sort(order.begin() + 8 * sl, order.begin() + std::min(M, 8 * sl + 8));
     TSR_HIP(hipSetDevice(ctx->device));
     MxBank *mb = new MxBank;
-    mb->KBF = KBF; mb->ROWS = ROWS; mb->NKB = NKB; mb->NR = NR; mb->Lmin = Lmin; mb->Lmax = bank->Lmax;
+    mb->KBF = KBF; mb->ROWS = ROWS; mb->NR = NR; mb->Lmin = Lmin; mb->Lmax = bank->Lmax;
     mb->CH = CH; mb->nfull = nfull; mb->packed = packed; mb->n_phase = n_phase; mb->pw = pw; mb->n_slice = n_slice;
     std::vector<MxCol> cols((size_t)16 * n_slice);
     std::vector<double> scale(M);
@@ -703,61 +706,86 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
         }
         if (std::max(pos, neg) >= 16777216.0) mb->exact = false;
     }
-    for (int sl = 0; sl < n_slice; ++sl)
+    std::vector<unsigned char> Bf;     // [slice][phase][K-block][digit][1536]
+    std::vector<int32_t> kq;           // [slice][K-block][4]
+    for (int sl = 0; sl < n_slice; ++sl) {
+        const int m0 = 8 * sl, ms = std::min(8, M - m0);
+        int rows_s = 1;
+        for (int i = 0; i < ms; ++i) rows_s = std::max(rows_s, bank->L[order[m0 + i]] + 1);
+        std::vector<ChunkRef> refs;
+        for (int plane = 0; plane < 2; ++plane) {
+            for (int rho = plane; rho < rows_s; rho += 2)
+                for (int c = 0; c < (packed ? nfull : CHw); ++c) refs.push_back(ChunkRef{plane, c, rho, 0});
+            if (packed)
+                for (int k0 = 0; plane + 2 * k0 < rows_s; k0 += 4) refs.push_back(ChunkRef{plane, nfull, -1, k0});
+        }
+        const int NKB = std::max(3 * MX_WAVES, (int)((refs.size() + 3) / 4));   // (every wave starts with three K-blocks)
+        while ((int)refs.size() < 4 * NKB) refs.push_back(ChunkRef{0, 0, -2, 0});   // filler: zero weights, any valid chunk
+        if (n_slice == 1 && (int)((size_t)rows_s * (packed ? nfull : CHw)) < 4 * 3 * MX_WAVES) {   // (short filters on narrow rows: mostly filler -- the int8 kernels serve those)
+            delete mb;
+            bank->mx_unsupported = true;
+            return TSR_ERR_UNSUPPORTED;
+        }
+        mb->slice_NKB.push_back(NKB);
+        mb->slice_kq.push_back(kq.size());
+        mb->slice_B.push_back(Bf.size());
         for (int n = 0; n < 16; ++n) {
-            const int m = 8 * sl + (n & 7);
-            if (m < M) cols[(size_t)16 * sl + n] = MxCol{(float)(1.0 / scale[m]), (float)bank->c[m], bank->L[m], m};
-            else cols[(size_t)16 * sl + n] = MxCol{0.0f, -INFINITY, 1 << 30, 0x7ffffffe};
+            const int i = n & 7;
+            if (i < ms) {
+                const int m = order[m0 + i];
+                cols[(size_t)16 * sl + n] = MxCol{(float)(1.0 / scale[m]), (float)bank->c[m], bank->L[m], m};
+            } else cols[(size_t)16 * sl + n] = MxCol{0.0f, -INFINITY, 1 << 30, 0x7ffffffe};
         }
-    std::vector<unsigned char> Bf((size_t)n_slice * n_phase * NKB * 3 * 1536, 0);   // [slice][phase][K-block][digit]
-    std::vector<int32_t> kq((size_t)NKB * 4);
-    for (int kb = 0; kb < NKB; ++kb)
-        for (int q = 0; q < 4; ++q) {
-            const ChunkRef &cr = refs[(size_t)kb * 4 + q];
-            const int row = cr.rho >= 0 ? (cr.rho >> 1) : cr.rho == -1 ? cr.k0 : 0;   // rows behind the pair's first frame row
-            kq[(size_t)kb * 4 + q] = ((cr.plane * CH + cr.c) * NR + row) << 4;
-        }
-    for (int sl = 0; sl < n_slice; ++sl)
-    for (int ph = 0; ph < n_phase; ++ph)
-    for (int kb = 0; kb < NKB; ++kb) {
-        for (int lane = 0; lane < 64; ++lane) {
-            const int n = lane & 15, q = lane >> 4, s = n >> 3, m = 8 * sl + (n & 7);
-            const ChunkRef &cr = refs[(size_t)kb * 4 + q];
-            uint32_t str[3][6] = {{0}};
-            if (m < M && cr.rho != -2) {
-                for (int e = 0; e < 32; ++e) {
-                    int tau;
-                    int64_t f;
-                    if (cr.rho >= 0) {          // element 8 k + j = feature 4 j + k of the chunk (the order the bit rows expand to)
-                        tau = cr.rho - s;
-                        f = 32 * (int64_t)cr.c + 4 * (e & 7) + (e >> 3);
-                    } else {                    // leftover chunk: bit v = 4 j + k of lo(r) | lo(r+1) << 8 | ...: tap row k0 + (v >> 3), feature v & 7
-                        const int v = 4 * (e & 7) + (e >> 3);
-                        tau = cr.plane + 2 * (cr.k0 + (v >> 3)) - s;
-                        f = 32 * (int64_t)nfull + (v & 7);
-                    }
-                    if (f >= Dph) continue;
-                    f += (int64_t)ph * Dph;     // (the phase's features)
-                    if (f >= D || tau < 0 || tau >= bank->L[m]) continue;
-                    const float w = bank->W_cat[(size_t)(woff[m] + (int64_t)tau * D + f)];
-                    const long v = lrint((double)w * scale[m]);
-                    const long l2 = (v + 128) >> 8;              // (arithmetic shift: floor) -16 .. 16
-                    const long r = v - 256 * l2;                 // -128 .. 127
-                    const long l1 = (r + 8) >> 4;                // -8 .. 8
-                    const long l0 = r - 16 * l1;                 // -8 .. 7
-                    const int dg[3] = {(int)l0, (int)l1, (int)l2};
-                    for (int l = 0; l < 3; ++l) {
-                        const uint32_t code = (uint32_t)fp6_code(dg[l]);
-                        const int bit = 6 * e;
-                        str[l][bit >> 5] |= code << (bit & 31);
-                        if ((bit & 31) > 26) str[l][(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+        for (int kb = 0; kb < NKB; ++kb)
+            for (int q = 0; q < 4; ++q) {
+                const ChunkRef &cr = refs[(size_t)kb * 4 + q];
+                const int row = cr.rho >= 0 ? (cr.rho >> 1) : cr.rho == -1 ? cr.k0 : 0;   // rows behind the pair's first frame row
+                kq.push_back(((cr.plane * CH + cr.c) * NR + row) << 4);
+            }
+        const size_t base = Bf.size();
+        Bf.resize(base + (size_t)n_phase * NKB * 3 * 1536, 0);
+        for (int ph = 0; ph < n_phase; ++ph)
+        for (int kb = 0; kb < NKB; ++kb) {
+            for (int lane = 0; lane < 64; ++lane) {
+                const int n = lane & 15, q = lane >> 4, s = n >> 3, i = n & 7;
+                const ChunkRef &cr = refs[(size_t)kb * 4 + q];
+                uint32_t str[3][6] = {{0}};
+                if (i < ms && cr.rho != -2) {
+                    const int m = order[m0 + i];
+                    for (int e = 0; e < 32; ++e) {
+                        int tau;
+                        int64_t f;
+                        if (cr.rho >= 0) {          // element 8 k + j = feature 4 j + k of the chunk (the order the bit rows expand to)
+                            tau = cr.rho - s;
+                            f = 32 * (int64_t)cr.c + 4 * (e & 7) + (e >> 3);
+                        } else {                    // leftover chunk: bit v = 4 j + k of lo(r) | lo(r+1) << 8 | ...: tap row k0 + (v >> 3), feature v & 7
+                            const int v = 4 * (e & 7) + (e >> 3);
+                            tau = cr.plane + 2 * (cr.k0 + (v >> 3)) - s;
+                            f = 32 * (int64_t)nfull + (v & 7);
+                        }
+                        if (f >= Dph) continue;
+                        f += (int64_t)ph * Dph;     // (the phase's features)
+                        if (f >= D || tau < 0 || tau >= bank->L[m]) continue;
+                        const float w = bank->W_cat[(size_t)(woff[m] + (int64_t)tau * D + f)];
+                        const long v = lrint((double)w * scale[m]);
+                        const long l2 = (v + 128) >> 8;              // (arithmetic shift: floor) -16 .. 16
+                        const long r = v - 256 * l2;                 // -128 .. 127
+                        const long l1 = (r + 8) >> 4;                // -8 .. 8
+                        const long l0 = r - 16 * l1;                 // -8 .. 7
+                        const int dg[3] = {(int)l0, (int)l1, (int)l2};
+                        for (int l = 0; l < 3; ++l) {
+                            const uint32_t code = (uint32_t)fp6_code(dg[l]);
+                            const int bit = 6 * e;
+                            str[l][bit >> 5] |= code << (bit & 31);
+                            if ((bit & 31) > 26) str[l][(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+                        }
                     }
                 }
-            }
-            for (int l = 0; l < 3; ++l) {
-                unsigned char *dst = Bf.data() + ((((size_t)sl * n_phase + ph) * NKB + kb) * 3 + l) * 1536;
-                memcpy(dst + lane * 16, &str[l][0], 16);
-                memcpy(dst + 1024 + lane * 8, &str[l][4], 8);
+                for (int l = 0; l < 3; ++l) {
+                    unsigned char *dst = Bf.data() + base + (((size_t)ph * NKB + kb) * 3 + l) * 1536;
+                    memcpy(dst + lane * 16, &str[l][0], 16);
+                    memcpy(dst + 1024 + lane * 8, &str[l][4], 8);
+                }
             }
         }
     }
@@ -994,14 +1022,13 @@ int tsr_launch_mx_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, float
     TSR_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS));
     MxArgs a;
     a.bits = mc->ext_bits ? mc->ext_bits : mc->d_bits; a.B = mb->d_B;
-    a.n_phase = mb->n_phase; a.DWr = mc->DWr; a.bits_phase = mc->bits_phase; a.B_phase = (long long)mb->NKB * 3 * 1536; a.groups = mc->d_groups; a.wg = mc->d_wg; a.cols = mb->d_cols;
+    a.n_phase = mb->n_phase; a.DWr = mc->DWr; a.bits_phase = mc->bits_phase; a.groups = mc->d_groups; a.wg = mc->d_wg; a.cols = mb->d_cols;
     // (development override, read once per process: TSR_MX_SLOWCAP)
     static const int slow_cap_env = [] { const char *e = getenv("TSR_MX_SLOWCAP"); return e ? atoi(e) : 0; }();
-    a.slow_cap = slow_cap_env > 0 ? slow_cap_env : (mb->NKB * 13 + 63) / 64 / 2 + 1;
     a.fixed = mb->exact ? 0 : 1;
     a.scores = d_scores; a.ids = d_ids; a.all = d_all; a.P = cp->P; a.M = bank->M;
-    a.kq = mb->d_kq; a.CH = mb->CH; a.nfull = mb->nfull; a.packed = mb->packed;
-    a.n_groups = mc->n_groups; a.NKB = mb->NKB; a.KBF = mb->KBF; a.NR = mb->NR; a.Lmin = mb->Lmin; a.idmax = mb->idmax; a.cmax = mb->cmax;
+    a.CH = mb->CH; a.nfull = mb->nfull; a.packed = mb->packed;
+    a.n_groups = mc->n_groups; a.KBF = mb->KBF; a.NR = mb->NR; a.Lmin = mb->Lmin; a.idmax = mb->idmax; a.cmax = mb->cmax;
     TSR_REQUIRE((size_t)32 * mb->CH * mb->NR <= (size_t)MX_IMAGE && (size_t)MX_NT * 7 * 1024 <= (size_t)MX_IMAGE, "TSR_MX: LDS image too large");
     TSR_REQUIRE(2 * mb->KBF * mb->NR <= 5 * MX_WAVES * 64, "TSR_MX: more rows than the staging covers");
     const size_t lds = MX_LDS;
@@ -1013,7 +1040,11 @@ int tsr_launch_mx_bank(tsr_ctx *ctx, const tsr_bank *bank, tsr_corpus *cp, float
 #endif
     // one launch per slice of eight templates; the second and later ones merge into the result arrays (max mode)
     for (int sl = 0; sl < mb->n_slice; ++sl) {
-        a.B = mb->d_B + (size_t)sl * mb->n_phase * mb->NKB * 3 * 1536;
+        a.NKB = mb->slice_NKB[(size_t)sl];
+        a.B = mb->d_B + mb->slice_B[(size_t)sl];
+        a.B_phase = (long long)a.NKB * 3 * 1536;
+        a.kq = mb->d_kq + mb->slice_kq[(size_t)sl];
+        a.slow_cap = slow_cap_env > 0 ? slow_cap_env : (a.NKB * 13 + 63) / 64 / 2 + 1;
         a.cols = mb->d_cols + 16 * sl;
         a.M = std::min(8, bank->M - 8 * sl);
         a.merge = sl > 0;
