@@ -35,6 +35,7 @@
 #include <algorithm>
 #include <cmath>
 
+#include "mx_plan.h"
 #include "tsr_internal.h"
 
 namespace {
@@ -52,12 +53,6 @@ constexpr int MX_MAX_KBF = 4;     // feature rows of up to 512 features
 constexpr int MX_MAX_SLICES = 32;  // banks of up to 256 templates (eight per launch)
 constexpr int MX_QMAX = 4095;     // |fixed-point weight|
 
-struct MxGroup {   // one tile row: the window starts t0 and t0 + 1 of one utterance
-    int32_t v0;    // virtual position of t0 (utterances padded to even lengths: v0 is even)
-    int32_t p0;    // stream frame of t0
-    int32_t rem;   // frames the utterance has left from t0 on (T - t0)
-    int32_t pad;
-};
 struct MxCol {     // one of the 16 columns: (shift s = n >> 3, template m = n & 7)
     float inv_scale, c;
     int32_t L, id;
@@ -819,8 +814,7 @@ static int mx_build_rows(tsr_ctx *ctx, tsr_corpus *cp, MxCorpus *mc, int DW, int
         mc->d_bits = nullptr;
     }
     mc->DW = 0;
-    mc->voff.assign((size_t)N + 1, 0);
-    for (int64_t u = 0; u < N; ++u) mc->voff[(size_t)u + 1] = mc->voff[(size_t)u] + ((cp->offsets[(size_t)u + 1] - cp->offsets[(size_t)u] + 1) & ~(int64_t)1);
+    mx_virtual_offsets(cp->offsets.data(), N, mc->voff);   // (csrc/mx_plan.h)
     mc->Pv = mc->voff[(size_t)N];
     mc->rows_alloc = mc->Pv + 2 * (MX_LDS / 128 / 16 * 16) + 2;   // read-ahead of the last workgroup: at most one LDS image of rows
     const int row_dw = pw ? pw : DW, planes = pw ? n_phase : 1;
@@ -914,74 +908,24 @@ static int mx_corpus_plan(tsr_ctx *ctx, tsr_corpus *cp, const MxBank *mb)
         mc->plan_unsupported = unsupported;
         return unsupported ? TSR_ERR_UNSUPPORTED : TSR_OK;
     };
-    // A tile is 16 consecutive records.  Where 16 pairs would span more rows than an LDS image holds (utterances barely longer
-    // than the filters give one pair per T rows), the tile is closed early and filled up with records that score nothing
-    // (rem = 0: no window, no frame of their own), so that every tile fits a workgroup whatever the utterance lengths are.
-    std::vector<MxGroup> groups;
-    const int64_t span_max = 2 * (int64_t)mb->NR;
-    int in_tile = 0;
-    int64_t tile_v0 = 0;
-    for (int64_t u = 0; u < cp->N; ++u) {
-        const int64_t T = cp->offsets[(size_t)u + 1] - cp->offsets[(size_t)u];
-        if (T <= 0) continue;
-        const int64_t ng = (std::max<int64_t>(T - mb->Lmin + 1, 1) + 1) / 2;
-        for (int64_t g = 0; g < ng; ++g) {
-            const int64_t v0 = mc->voff[(size_t)u] + 2 * g, p0 = cp->offsets[(size_t)u] + 2 * g;
-            if (v0 > INT32_MAX - 4096 || groups.size() > (size_t)INT32_MAX / 32) return keep(true);
-            if (in_tile == 16) in_tile = 0;
-            if (in_tile > 0 && v0 + mb->ROWS - tile_v0 > span_max) {
-                const MxGroup last = groups.back();
-                for (; in_tile < 16; ++in_tile) groups.push_back(MxGroup{last.v0, last.p0, 0, 0});
-                in_tile = 0;
-            }
-            if (in_tile == 0) tile_v0 = v0;
-            groups.push_back(MxGroup{(int32_t)v0, (int32_t)p0, (int32_t)std::min<int64_t>(T - 2 * g, INT32_MAX), 0});
-            ++in_tile;
-        }
-    }
-    const int64_t n_groups = (int64_t)groups.size(), n_tiles = (n_groups + 15) / 16;
-    std::vector<int4> wgs;
-    auto span_end = [&](int64_t tile_last) {   // one past the last virtual row the tiles up to tile_last read
-        const int64_t gl = std::min<int64_t>(n_groups, (tile_last + 1) * 16) - 1;
-        return (int64_t)groups[(size_t)gl].v0 + mb->ROWS;
-    };
-    // Tiles per workgroup.  A launch takes as long as its slowest CU: with one workgroup per CU and round, the tiles are
-    // spread evenly over (CUs x rounds) workgroups instead of filling each to MX_NT -- 5438 tiles are two rounds of 11 per
-    // workgroup (512 slots), not one round of 21 and a second one for the three workgroups that did not fit (which costs a
-    // whole round: measured 44 vs 24 us at config 2's size with Lmin = 28).  Where the image's span cuts workgroups short,
-    // the count can still exceed the slots: one more round, smaller shares, until it fits.
-    const int64_t n_cu = std::max(1, ctx->cus);
-    int64_t rounds = std::max<int64_t>(1, (n_tiles + n_cu * MX_NT - 1) / (n_cu * MX_NT));
-    for (;; ++rounds) {
-        const int64_t target = std::min<int64_t>(MX_NT, std::max<int64_t>(1, (n_tiles + n_cu * rounds - 1) / (n_cu * rounds)));
-        wgs.clear();
-        bool stuck = false;
-        for (int64_t t = 0; t < n_tiles;) {
-            const int64_t v_lo = groups[(size_t)(t * 16)].v0;
-            int64_t cnt = 0;
-            while (cnt < target && t + cnt < n_tiles && span_end(t + cnt) - v_lo <= span_max) ++cnt;
-            if (cnt == 0) {   // (cannot happen: tiles are closed before they outgrow the image, and ROWS + 34 <= 2 NR)
-                stuck = true;
-                break;
-            }
-            wgs.push_back(make_int4((int)t, (int)cnt, (int)v_lo, (int)(span_end(t + cnt - 1) - v_lo)));
-            t += cnt;
-        }
-        if (stuck) return keep(true);
-        mc->plan_target = (int)target;
-        if ((int64_t)wgs.size() <= n_cu * rounds || target == 1) break;
-    }
-    for (const int4 &w : wgs)
-        if ((int64_t)w.z + w.w > mc->rows_alloc) {   // (cannot happen: the slack behind the bit rows is one LDS image)
+    static_assert(sizeof(MxWg) == sizeof(int4), "the kernel reads a workgroup record as one int4");
+    MxPlan pl = mx_make_plan(cp->offsets.data(), mc->voff.data(), cp->N, mb->Lmin, mb->ROWS, mb->NR, ctx->cus, MX_NT);   // (csrc/mx_plan.h)
+    if (pl.unsupported) return keep(true);
+    mc->plan_target = pl.target;
+    const std::vector<MxGroup> &groups = pl.groups;
+    const std::vector<MxWg> &wgs = pl.wgs;
+    const int64_t n_groups = (int64_t)groups.size();
+    for (const MxWg &w : wgs)
+        if ((int64_t)w.v_lo + w.nfr > mc->rows_alloc) {   // (cannot happen: the slack behind the bit rows is one LDS image)
             return keep(true);
         }
     mc->n_groups = (int)n_groups;
     mc->n_wg = (int)wgs.size();
     if (n_groups) {
         TSR_HIP(hipMalloc(reinterpret_cast<void **>(&mc->d_groups), groups.size() * sizeof(MxGroup)));
-        TSR_HIP(hipMalloc(reinterpret_cast<void **>(&mc->d_wg), wgs.size() * sizeof(int4)));
+        TSR_HIP(hipMalloc(reinterpret_cast<void **>(&mc->d_wg), wgs.size() * sizeof(MxWg)));
         TSR_HIP(hipMemcpyAsync(mc->d_groups, groups.data(), groups.size() * sizeof(MxGroup), hipMemcpyHostToDevice, ctx->stream));
-        TSR_HIP(hipMemcpyAsync(mc->d_wg, wgs.data(), wgs.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+        TSR_HIP(hipMemcpyAsync(mc->d_wg, wgs.data(), wgs.size() * sizeof(MxWg), hipMemcpyHostToDevice, ctx->stream));
         TSR_HIP(hipStreamSynchronize(ctx->stream));
     }
     return keep(false);

@@ -14,7 +14,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fvisibility=hi
 # per-source extras: matrix instructions with VGPR accumulators (with AGPR accumulators the register allocator
 # rotates the three accumulator tiles of detect_exact_mfma.hip through sixteen copies per loop iteration)
 EXTRA = {"detect_exact_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
-HEADERS = [os.path.join(CSRC, "tsr_internal.h"), os.path.join(CSRC, "detect_mfma_kernel.inc"), os.path.join(CSRC, "detect_mfma_tap2.inc"),
+HEADERS = [os.path.join(CSRC, "tsr_internal.h"), os.path.join(CSRC, "mx_plan.h"), os.path.join(CSRC, "detect_mfma_kernel.inc"), os.path.join(CSRC, "detect_mfma_tap2.inc"),
            os.path.join(os.path.dirname(PKG), "include", "tsr.h")]
 
 
