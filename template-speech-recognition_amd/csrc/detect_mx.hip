@@ -586,12 +586,6 @@ __global__ __launch_bounds__(MX_WAVES * 64, 2) void mx_bank_kernel(const MxArgs 
 inline MxBank *mxb(const tsr_bank *b) { return static_cast<MxBank *>(b->mx); }
 inline MxCorpus *mxc(const tsr_corpus *c) { return static_cast<MxCorpus *>(c->mx); }
 
-int fp6_code(int d)   // digit / 8 as e2m3: magnitudes 0 .. 15 are their own code, 16 (= 2.0) is exponent 2, mantissa 0
-{
-    const int mag = d < 0 ? -d : d;
-    return (mag & 31) | (d < 0 ? 0x20 : 0);
-}
-
 }  // namespace
 
 void tsr_mx_bank_free(tsr_bank *bank)
@@ -763,13 +757,10 @@ static int mx_bank_build(tsr_ctx *ctx, tsr_bank *bank)
                         if (f >= D || tau < 0 || tau >= bank->L[m]) continue;
                         const float w = bank->W_cat[(size_t)(woff[m] + (int64_t)tau * D + f)];
                         const long v = lrint((double)w * scale[m]);
-                        const long l2 = (v + 128) >> 8;              // (arithmetic shift: floor) -16 .. 16
-                        const long r = v - 256 * l2;                 // -128 .. 127
-                        const long l1 = (r + 8) >> 4;                // -8 .. 8
-                        const long l0 = r - 16 * l1;                 // -8 .. 7
-                        const int dg[3] = {(int)l0, (int)l1, (int)l2};
+                        int dg[3];
+                        mx_digits(v, dg);   // (csrc/mx_plan.h)
                         for (int l = 0; l < 3; ++l) {
-                            const uint32_t code = (uint32_t)fp6_code(dg[l]);
+                            const uint32_t code = (uint32_t)mx_fp6_code(dg[l]);
                             const int bit = 6 * e;
                             str[l][bit >> 5] |= code << (bit & 31);
                             if ((bit & 31) > 26) str[l][(bit >> 5) + 1] |= code >> (32 - (bit & 31));

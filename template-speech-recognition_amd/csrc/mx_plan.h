@@ -93,3 +93,23 @@ inline MxPlan mx_make_plan(const int64_t *offsets, const int64_t *voff, int64_t 
     }
     return pl;
 }
+
+// ---- the weights' arithmetic (host side of the operand build) ------------------------------------------------------
+// A fixed-point weight |v| <= 4095 as three balanced radix-16 digits, v = d0 + 16 d1 + 256 d2 with d0 in -8 .. 7,
+// d1 in -8 .. 8, d2 in -16 .. 16: every digit / 8 is an exact fp6 (e2m3) value, the instruction's block scales carry
+// 2^3, 2^7 and 2^11.
+inline void mx_digits(long v, int d[3])
+{
+    const long l2 = (v + 128) >> 8;   // (arithmetic shift: floor)
+    const long r = v - 256 * l2;      // -128 .. 127
+    const long l1 = (r + 8) >> 4;
+    const long l0 = r - 16 * l1;
+    d[0] = (int)l0; d[1] = (int)l1; d[2] = (int)l2;
+}
+// digit / 8 as e2m3 (sign, two exponent bits of bias 1, three mantissa bits): magnitudes 0 .. 15 are their own code
+// (subnormals 0 .. 7 / 8, then 1.xxx), 16 (= 2.0) is exponent 2 with mantissa 0
+inline int mx_fp6_code(int d)
+{
+    const int mag = d < 0 ? -d : d;
+    return (mag & 31) | (d < 0 ? 0x20 : 0);
+}

@@ -1,4 +1,4 @@
-// Invariants of the TSR_MX host plan (template-speech-recognition_amd/csrc/mx_plan.h) on random corpora -- built and run
+// Invariants of the TSR_MX host plan and of its weight arithmetic (template-speech-recognition_amd/csrc/mx_plan.h) -- built and run
 // by tests/test_mx_plan_cpu.py with g++ (-fsanitize=address,undefined), no device involved.
 //   ./mx_plan_check <cases> <seed>      prints "ok <cases> cases" or the first violated invariant
 #include <cstdio>
@@ -85,8 +85,33 @@ static int check(const std::vector<int64_t> &offs, int Lmin, int ROWS, int NR, i
     return 0;
 }
 
+// e2m3 as the matrix instruction reads it: sign, exponent (bias 1), three mantissa bits
+static double fp6_value(int code)
+{
+    const int e = (code >> 3) & 3, m = code & 7;
+    const double mag = e == 0 ? m / 8.0 : (1.0 + m / 8.0) * (double)(1 << (e - 1));
+    return (code & 0x20) ? -mag : mag;
+}
+
+static int check_digits()
+{
+    for (long v = -4095; v <= 4095; ++v) {
+        int d[3];
+        mx_digits(v, d);
+        if (d[0] < -8 || d[0] > 7 || d[1] < -8 || d[1] > 8 || d[2] < -16 || d[2] > 16) return fail("digit out of range", v);
+        if (d[0] + 16L * d[1] + 256L * d[2] != v) return fail("digits do not recompose", v);
+        // what the instruction computes: fp6 value x block scale (2^3, 2^7, 2^11), summed
+        const double got = fp6_value(mx_fp6_code(d[0])) * 8.0 + fp6_value(mx_fp6_code(d[1])) * 128.0 + fp6_value(mx_fp6_code(d[2])) * 2048.0;
+        if (got != (double)v) return fail("fp6 codes x block scales do not give the weight", v);
+    }
+    for (int d = -16; d <= 16; ++d)
+        if ((mx_fp6_code(d) & ~0x3f) || fp6_value(mx_fp6_code(d)) != d / 8.0) return fail("fp6 code of a digit", d);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (check_digits()) return 1;
     const int cases = argc > 1 ? std::atoi(argv[1]) : 200;
     std::mt19937_64 rng(argc > 2 ? std::strtoull(argv[2], nullptr, 10) : 1);
     auto uni = [&](int lo, int hi) { return (int)(lo + rng() % (uint64_t)(hi - lo + 1)); };
