@@ -357,6 +357,8 @@ def two_streams(corpus, flags, device, copies=48, passes=12):
             cp.close()
     for bk in banks:
         bk.close()
+    for x in ctxs:
+        x.close()
     return {"streams": 2, "copies_per_stream": copies, "us_per_launch_one_stream_wall": one * 1e6, "us_per_launch_two_streams_wall": two * 1e6,
             "frames_per_s": frames / two, "speedup_over_one_stream": one / two, "hbm_gbs_alg": ALG_BYTES_PER_FRAME * frames / two / 1e9,
             "frac_of_hbm_peak": ALG_BYTES_PER_FRAME * frames / two / 1e9 / HBM_PEAK_GBS, "first_and_last_copy_score_alike": same,
