@@ -305,10 +305,10 @@ def long_corpus(ctx, corpus, bank, flags, times=10):
     feats = np.concatenate([corpus["feats"]] * times)
     offs = np.concatenate([corpus["offsets"][:-1] + k * int(corpus["offsets"][-1]) for k in range(times)] +
                           [np.array([times * int(corpus["offsets"][-1])], np.int64)])
-    big = [tsr_hip.Corpus(feats, offs, ctx=ctx) for _ in range(2)]   # two copies: 1.5 GB, streamed from HBM alternately
+    big = [tsr_hip.Corpus(feats, offs, ctx=ctx) for _ in range(6)]   # six copies (4.3 GB of byte rows, 0.6 GB of bit rows: past the 256 MiB Infinity Cache), scored in turn
     del feats
-    time_launches(ctx, big, bank, flags, 10)            # (the first timed loops of a process run ~5 % slower than the later ones: clocks)
-    ms, _ = time_launches(ctx, big, bank, flags, 20)
+    time_launches(ctx, big, bank, flags, 4)             # (the first timed loops of a process run ~5 % slower than the later ones: clocks)
+    ms, _ = time_launches(ctx, big, bank, flags, 8)
     frames = int(offs[-1])
     s0, _ = big[0].download()
     same = bool(np.array_equal(s0[:int(corpus["offsets"][-1])], s0[-int(corpus["offsets"][-1]):]))   # first and last copy of the corpus
